@@ -1,0 +1,120 @@
+/* mvnerf_hip.h - C ABI of libmvnerf_hip.so: the MI355X (gfx950) implementation of the volumetric
+ * rendering hot path of TWeber132/thesis-clip-nerf (src/lib/mvnerf).
+ *
+ * The reference has no FFI on this path: it is Python calling TensorFlow ops.  Each entry point
+ * below therefore names the reference Python function it replaces (file:line under
+ * /root/reference/src/lib); INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32/int32 unless marked [host]; tensors are dense,
+ *    row-major, in the shapes the reference uses (B scenes, V source views, R rays, S samples);
+ *  - the caller owns every buffer; nothing is allocated, freed or retained by the library;
+ *  - `stream` is a hipStream_t (NULL = default stream); all work is stream-ordered and asynchronous;
+ *  - return value 0 = success; < 0 = argument error (MVNERF_E_*); > 0 = hipError_t of a failed
+ *    launch.  mvnerf_last_error() returns a thread-local description of the last failure.
+ */
+#ifndef MVNERF_HIP_H
+#define MVNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mvnerf_stream_t; /* hipStream_t */
+
+#define MVNERF_NET_PARAMS 247300   /* floats of one MLP in Keras order, see mvnerf_pack_net */
+#define MVNERF_N_FEATURES 256
+#define MVNERF_HIDDEN 128
+
+#define MVNERF_E_ARG (-1)          /* null pointer / non-positive size */
+#define MVNERF_E_SHAPE (-2)        /* unsupported shape (message says which) */
+#define MVNERF_E_ALIGN (-3)        /* pointer not 16-byte aligned where required */
+
+#define MVNERF_Q7_ZERO 0           /* sample_pdf: out-of-range gather yields 0 (TF-GPU gather_nd) */
+#define MVNERF_Q7_CLAMP 1          /* sample_pdf: clamp `above` to the last bin */
+
+int mvnerf_abi_version(void);
+const char* mvnerf_last_error(void);
+
+/* Number of floats of the MFMA-ordered weight image produced by mvnerf_pack_net. */
+size_t mvnerf_packed_net_floats(void);
+
+/* Re-lay one MLP (MVResNetMLPNeRFEmbedding + RenderReadout, layers.py:334-397) from Keras order
+ *   W0[379,128] b0[128] | 6 x (W1[128,128] b1[128] W2[128,128] b2[128]) | Wr[128,4] br[4]
+ * (kernel[in,out], bias[out]; 247300 floats) into the operand order the MFMA kernel streams.
+ * Call once per weight update.  `packed` must be 16-byte aligned. */
+int mvnerf_pack_net(const float* net_keras, float* packed, mvnerf_stream_t stream);
+
+/* get_specific_rays / get_rays (nerf_utils.py:15-35).  d = normalize(M * [u, v, 1]) in float64,
+ * rounded to fp32 on store; o = origin.  M = E[:3,:3] @ inv(K[:3,:3]) and origin = E[:3,3] are
+ * [host] float64 (the 3x3 inverse stays in NumPy/LAPACK on the host, as in the reference).
+ * If u and v are NULL the full image grid is generated: ray n = (v = n / width, u = n % width)
+ * for n < width*height (get_rays); otherwise n_rays pixels (u[n], v[n]) (get_specific_rays).
+ * rays_o, rays_d: (n_rays,3) fp32.  rays_d64 (optional, may be NULL): (n_rays,3) float64. */
+int mvnerf_get_rays(const double* m3x3_host, const double* origin_host, const float* u, const float* v,
+                    int n_rays, int width, int normalize, float* rays_o, float* rays_d, double* rays_d64,
+                    mvnerf_stream_t stream);
+
+/* sample_along_ray depths (nerf_utils.py:49-58): z[n,i] = fl32(near + i*step) + u[n,i]*fl32(step),
+ * step = (far-near)/n_samples in float64.  u, z: (n_rays, n_samples). */
+int mvnerf_stratified_depths(const float* u, int n_rays, int n_samples, double near_, double far_,
+                             float* z, mvnerf_stream_t stream);
+
+/* One evaluation pass of the radiance field (model_v0.py:122-144 coarse, :157-180 fine):
+ *   p = o + z*d                              (nerf_utils.py:59-60 / model_v0.py:157-158)
+ *   per view: cam = Einv*[p;1], pix = K4*cam (compute_pixel_in_image_mv, nerf_utils.py:64-81)
+ *             bilinear gather of [2*img-1 | features] at pix (get_projection_features_mv,
+ *             nerf_utils.py:277-285 -> tensorflow_addons interpolate_bilinear, indexing='xy')
+ *             cam_dir = Einv*[d;1]           (world_to_camera_direction_vector_mv, :84-105)
+ *             PE(cam xyz), PE(cam_dir)       (position_encoding, nerf_utils.py:108-126)
+ *             Dense 379->128 + 3 ResNet blocks                       (layers.py:354-366)
+ *   mean over views, 3 ResNet blocks         (layers.py:368-374)
+ *   Dense 128->4, sigmoid / softplus         (RenderReadout, layers.py:392-397)
+ * rays_o, rays_d (B,R,3); z (B,R,S); images (B,V,H,W,3) in [0,1]; features (B,V,H,W,256), 16-byte
+ * aligned; intrinsics, extrinsics_inv (B,V,4,4); packed_net from mvnerf_pack_net.
+ * rgbs (B,R,S,4) = (r,g,b,sigma) per sample, 16-byte aligned.
+ * tap_idx (optional, may be NULL): (B,V,R,S,4) int32 linear texel indices
+ * (b*V+v)*H*W + y*W + x of the tl,tr,bl,br taps (the integer contract of a6).
+ * pix (optional, may be NULL): (B,V,R,S,2) fp32 pixel locations (x,y). */
+int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                      const float* features, const float* intrinsics, const float* extrinsics_inv,
+                      const float* packed_net, int B, int V, int R, int S, int H, int W, float* rgbs,
+                      int32_t* tap_idx, float* pix, mvnerf_stream_t stream);
+
+/* MVVNeRFRenderer.volumetric_render (model_v0.py:89-100) with sigma_to_alpha (nerf_utils.py:129-140).
+ * z (n_rays,S); rgbs (n_rays,S,4); S in {64,128,192,256}.
+ * rgb (n_rays,3); depth (n_rays); weights (optional, may be NULL) (n_rays,S). */
+int mvnerf_composite(const float* z, const float* rgbs, int n_rays, int S, float* rgb, float* depth,
+                     float* weights, mvnerf_stream_t stream);
+
+/* Hierarchical resampling (model_v0.py:150-156): z_mid, probs = w[1:-1], sample_pdf
+ * (nerf_utils.py:143-176) with explicit uniforms u_fine, concat, ascending sort.
+ * z, weights, u_fine: (n_rays,64).  z_all: (n_rays,128).  Optional outputs (may be NULL):
+ * z_fine (n_rays,64) fp32, above / below (n_rays,64) int32 (the integer contract of a13). */
+int mvnerf_resample(const float* z, const float* weights, const float* u_fine, int n_rays, int S,
+                    int q7_mode, float* z_all, float* z_fine, int32_t* above, int32_t* below,
+                    mvnerf_stream_t stream);
+
+/* Bytes of scratch mvnerf_render_fwd needs for (B,R,S). */
+size_t mvnerf_render_workspace_bytes(int B, int R, int S);
+
+/* MVVNeRFRenderer._call (model_v0.py:113-184): stratified depths -> coarse field -> composite ->
+ * resample -> fine field -> composite, all on `stream`, no host synchronisation.
+ * u_coarse, u_fine (B,R,S) are the uniforms the reference draws inside the graph
+ * (nerf_utils.py:57,151), here explicit.  S must be 64.
+ * Outputs: rgb, fine_rgb (B,R,3); depth, fine_depth (B,R)  (the reference's 4-tuple, :184).
+ * workspace: 16-byte aligned, mvnerf_render_workspace_bytes(B,R,S) bytes. */
+int mvnerf_render_fwd(const float* rays_o, const float* rays_d, const float* images, const float* features,
+                      const float* intrinsics, const float* extrinsics_inv, const float* packed_coarse,
+                      const float* packed_fine, const float* u_coarse, const float* u_fine, int B, int V,
+                      int R, int S, int H, int W, double near_, double far_, int q7_mode, float* rgb,
+                      float* depth, float* fine_rgb, float* fine_depth, void* workspace,
+                      mvnerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVNERF_HIP_H */

@@ -1,0 +1,69 @@
+"""ctypes binding of libmvnerf_hip.so (include/mvnerf_hip.h).
+
+The HIP library is the product; there is no CPU or PyTorch fallback.  If the shared object is
+missing or fails to load, importing :func:`lib` raises ``RuntimeError`` telling the user to run
+``python -c "import __graft_entry__ as g; g.build()"`` (or ``make -C thesis_clip_nerf_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libmvnerf_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'mvnerf_hip.h')
+
+NET_PARAMS = 247300
+Q7_ZERO, Q7_CLAMP = 0, 1
+
+# name -> (restype, argtypes); must list every symbol include/mvnerf_hip.h declares
+# (tests/test_abi.py cross-checks this table against the header and the built library).
+SIGNATURES = {
+    'mvnerf_abi_version': (c_int, []),
+    'mvnerf_last_error': (c_char_p, []),
+    'mvnerf_packed_net_floats': (c_size_t, []),
+    'mvnerf_pack_net': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'mvnerf_get_rays': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
+    'mvnerf_stratified_depths': (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p]),
+    'mvnerf_field_eval': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p] * 4),
+    'mvnerf_composite': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mvnerf_resample': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
+    'mvnerf_render_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'mvnerf_render_fwd': (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_double, c_double, c_int] + [c_void_p] * 6),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle with argtypes set."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} not found: the HIP extension is not built and there is no fallback path. '
+            'Build it with `make -C thesis_clip_nerf_amd/csrc` (hipcc, gfx950) or `__graft_entry__.build()`.')
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise RuntimeError(f'cannot load {LIB_PATH}: {e}') from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return _lib
+
+
+def check(rc, what='mvnerf'):
+    """Map the C return code onto Python exceptions (<0: ValueError, >0: RuntimeError/HIP)."""
+    if rc == 0:
+        return
+    msg = lib().mvnerf_last_error().decode('utf-8', 'replace')
+    if rc < 0:
+        raise ValueError(f'{what}: {msg} (code {rc})')
+    raise RuntimeError(f'{what}: HIP error {rc}: {msg}')

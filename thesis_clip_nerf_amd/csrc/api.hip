@@ -1,0 +1,161 @@
+// extern "C" surface of libmvnerf_hip.so (include/mvnerf_hip.h): argument validation, launch
+// orchestration, error reporting.  No allocation, no host synchronisation, no global state besides
+// the thread-local error string; safe to call from one process per GPU on any stream.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/mvnerf_hip.h"
+#include "mvnerf_kernels.h"
+#include "mvnerf_math.h"
+#include "mvnerf_pack.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_status(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    return fail((int)e, "%s: %s", what, hipGetErrorString(e));
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+struct Workspace {          // carve-up of the caller's scratch for mvnerf_render_fwd (floats)
+    float *z, *rgbs_c, *weights, *z_all, *rgbs_f;
+    size_t bytes;
+};
+
+Workspace carve(void* base, long n_rays, int S) {
+    Workspace w;
+    float* p = static_cast<float*>(base);
+    const size_t n = (size_t)n_rays * S;
+    w.z = p;            p += n;
+    w.weights = p;      p += n;
+    w.z_all = p;        p += 2 * n;
+    w.rgbs_c = p;       p += 4 * n;
+    w.rgbs_f = p;       p += 8 * n;
+    w.bytes = (size_t)(p - static_cast<float*>(base)) * sizeof(float);
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvnerf_abi_version(void) { return 1; }
+
+const char* mvnerf_last_error(void) { return g_err; }
+
+size_t mvnerf_packed_net_floats(void) { return (size_t)mvnerf::kPackTotal; }
+
+int mvnerf_pack_net(const float* net_keras, float* packed, mvnerf_stream_t stream) {
+    if (!net_keras || !packed) return fail(MVNERF_E_ARG, "mvnerf_pack_net: null pointer");
+    if (!aligned16(packed)) return fail(MVNERF_E_ALIGN, "mvnerf_pack_net: packed must be 16-byte aligned");
+    return hip_status(mvnerf::launch_pack_net(net_keras, packed, static_cast<hipStream_t>(stream)), "mvnerf_pack_net");
+}
+
+int mvnerf_get_rays(const double* m3x3_host, const double* origin_host, const float* u, const float* v, int n_rays,
+                    int width, int normalize, float* rays_o, float* rays_d, double* rays_d64,
+                    mvnerf_stream_t stream) {
+    if (!m3x3_host || !origin_host || !rays_o || !rays_d) return fail(MVNERF_E_ARG, "mvnerf_get_rays: null pointer");
+    if ((u == nullptr) != (v == nullptr)) return fail(MVNERF_E_ARG, "mvnerf_get_rays: u and v must both be given or both NULL");
+    if (n_rays <= 0 || (!u && width <= 0)) return fail(MVNERF_E_ARG, "mvnerf_get_rays: n_rays=%d width=%d", n_rays, width);
+    return hip_status(mvnerf::launch_get_rays(m3x3_host, origin_host, u, v, n_rays, width, normalize, rays_o, rays_d,
+                                              rays_d64, static_cast<hipStream_t>(stream)),
+                      "mvnerf_get_rays");
+}
+
+int mvnerf_stratified_depths(const float* u, int n_rays, int n_samples, double near_, double far_, float* z,
+                             mvnerf_stream_t stream) {
+    if (!u || !z) return fail(MVNERF_E_ARG, "mvnerf_stratified_depths: null pointer");
+    if (n_rays <= 0 || n_samples <= 0) return fail(MVNERF_E_ARG, "mvnerf_stratified_depths: n_rays=%d n_samples=%d", n_rays, n_samples);
+    return hip_status(mvnerf::launch_stratified(u, (long)n_rays * n_samples, n_samples, near_, far_, z,
+                                                static_cast<hipStream_t>(stream)),
+                      "mvnerf_stratified_depths");
+}
+
+int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                      const float* features, const float* intrinsics, const float* extrinsics_inv,
+                      const float* packed_net, int B, int V, int R, int S, int H, int W, float* rgbs,
+                      int32_t* tap_idx, float* pix, mvnerf_stream_t stream) {
+    if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !packed_net || !rgbs)
+        return fail(MVNERF_E_ARG, "mvnerf_field_eval: null pointer");
+    if (B <= 0 || V <= 0 || R <= 0 || S <= 0) return fail(MVNERF_E_ARG, "mvnerf_field_eval: B=%d V=%d R=%d S=%d", B, V, R, S);
+    if (H < 2 || W < 2) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval: source image %dx%d, need H,W >= 2 (bilinear taps)", H, W);
+    const long total = (long)B * R * S;
+    if (total >= (1L << 31) || (long)B * V * H * W >= (1L << 31))
+        return fail(MVNERF_E_SHAPE, "mvnerf_field_eval: B*R*S=%ld or B*V*H*W too large for int32 indices", total);
+    if (!aligned16(features) || !aligned16(packed_net) || !aligned16(rgbs) || (tap_idx && !aligned16(tap_idx)))
+        return fail(MVNERF_E_ALIGN, "mvnerf_field_eval: features, packed_net, rgbs, tap_idx must be 16-byte aligned");
+    mvnerf::FieldParams p;
+    p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.images = images; p.features = features;
+    p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs; p.tap_idx = tap_idx; p.pix = pix;
+    p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W;
+    p.total = total;
+    p.n_tiles = (total + 31) / 32;
+    return hip_status(mvnerf::launch_field_eval(p, static_cast<hipStream_t>(stream)), "mvnerf_field_eval");
+}
+
+int mvnerf_composite(const float* z, const float* rgbs, int n_rays, int S, float* rgb, float* depth, float* weights,
+                     mvnerf_stream_t stream) {
+    if (!z || !rgbs || !rgb || !depth) return fail(MVNERF_E_ARG, "mvnerf_composite: null pointer");
+    if (n_rays <= 0) return fail(MVNERF_E_ARG, "mvnerf_composite: n_rays=%d", n_rays);
+    if (S % 64 != 0 || S < 64 || S > 256) return fail(MVNERF_E_SHAPE, "mvnerf_composite: S=%d, supported: 64,128,192,256", S);
+    if (!aligned16(rgbs)) return fail(MVNERF_E_ALIGN, "mvnerf_composite: rgbs must be 16-byte aligned");
+    return hip_status(mvnerf::launch_composite(z, rgbs, n_rays, S, rgb, depth, weights, static_cast<hipStream_t>(stream)),
+                      "mvnerf_composite");
+}
+
+int mvnerf_resample(const float* z, const float* weights, const float* u_fine, int n_rays, int S, int q7_mode,
+                    float* z_all, float* z_fine, int32_t* above, int32_t* below, mvnerf_stream_t stream) {
+    if (!z || !weights || !u_fine || !z_all) return fail(MVNERF_E_ARG, "mvnerf_resample: null pointer");
+    if (n_rays <= 0) return fail(MVNERF_E_ARG, "mvnerf_resample: n_rays=%d", n_rays);
+    if (S != 64) return fail(MVNERF_E_SHAPE, "mvnerf_resample: S=%d, only the reference's n_samples=64 is built", S);
+    if (q7_mode != MVNERF_Q7_ZERO && q7_mode != MVNERF_Q7_CLAMP) return fail(MVNERF_E_ARG, "mvnerf_resample: q7_mode=%d", q7_mode);
+    return hip_status(mvnerf::launch_resample(z, weights, u_fine, n_rays, q7_mode, z_all, z_fine, above, below,
+                                              static_cast<hipStream_t>(stream)),
+                      "mvnerf_resample");
+}
+
+size_t mvnerf_render_workspace_bytes(int B, int R, int S) {
+    if (B <= 0 || R <= 0 || S <= 0) return 0;
+    return carve(nullptr, (long)B * R, S).bytes;
+}
+
+int mvnerf_render_fwd(const float* rays_o, const float* rays_d, const float* images, const float* features,
+                      const float* intrinsics, const float* extrinsics_inv, const float* packed_coarse,
+                      const float* packed_fine, const float* u_coarse, const float* u_fine, int B, int V, int R,
+                      int S, int H, int W, double near_, double far_, int q7_mode, float* rgb, float* depth,
+                      float* fine_rgb, float* fine_depth, void* workspace, mvnerf_stream_t stream) {
+    if (!u_coarse || !u_fine || !rgb || !depth || !fine_rgb || !fine_depth || !workspace || !packed_fine)
+        return fail(MVNERF_E_ARG, "mvnerf_render_fwd: null pointer");
+    if (S != 64) return fail(MVNERF_E_SHAPE, "mvnerf_render_fwd: S=%d, only the reference's n_samples=64 is built", S);
+    if (B <= 0 || R <= 0) return fail(MVNERF_E_ARG, "mvnerf_render_fwd: B=%d R=%d", B, R);
+    if (!aligned16(workspace)) return fail(MVNERF_E_ALIGN, "mvnerf_render_fwd: workspace must be 16-byte aligned");
+    const long n_rays = (long)B * R;
+    if (n_rays * 2 * S >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_render_fwd: B*R*2S too large");
+    const Workspace w = carve(workspace, n_rays, S);
+    int rc;
+    if ((rc = mvnerf_stratified_depths(u_coarse, (int)n_rays, S, near_, far_, w.z, stream))) return rc;
+    if ((rc = mvnerf_field_eval(rays_o, rays_d, w.z, images, features, intrinsics, extrinsics_inv, packed_coarse, B, V,
+                                R, S, H, W, w.rgbs_c, nullptr, nullptr, stream)))
+        return rc;
+    if ((rc = mvnerf_composite(w.z, w.rgbs_c, (int)n_rays, S, rgb, depth, w.weights, stream))) return rc;
+    if ((rc = mvnerf_resample(w.z, w.weights, u_fine, (int)n_rays, S, q7_mode, w.z_all, nullptr, nullptr, nullptr, stream)))
+        return rc;
+    if ((rc = mvnerf_field_eval(rays_o, rays_d, w.z_all, images, features, intrinsics, extrinsics_inv, packed_fine, B,
+                                V, R, 2 * S, H, W, w.rgbs_f, nullptr, nullptr, stream)))
+        return rc;
+    return mvnerf_composite(w.z_all, w.rgbs_f, (int)n_rays, 2 * S, fine_rgb, fine_depth, nullptr, stream);
+}
+
+}  // extern "C"

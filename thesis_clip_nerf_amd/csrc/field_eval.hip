@@ -1,0 +1,309 @@
+// Fused radiance-field evaluation for gfx950 (MI355X):
+//   project -> bilinear gather -> positional encoding -> ResNet-MLP trunk -> read-out
+// for 32 samples per wavefront, activations resident in the register file, weights streamed from
+// L2 in MFMA operand order (mvnerf_pack.h), gathered features transposed through LDS.
+//
+// Reference being replaced: model_v0.py:122-144 / :157-180 (see include/mvnerf_hip.h,
+// mvnerf_field_eval).  One launch evaluates B*R*S samples; a wavefront owns 32 consecutive samples
+// (half a coarse ray, a quarter of a fine ray), waves are independent (no workgroup barrier).
+#include <hip/hip_runtime.h>
+
+#include "mvnerf_math.h"
+#include "mvnerf_pack.h"
+#include "mvnerf_kernels.h"
+
+namespace mvnerf {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kTile = 32;            // samples per wavefront (MFMA N dimension)
+constexpr int kWavesPerWG = 4;
+constexpr int kStageRow = 128;       // floats per staged sample row (half of the 256 channels)
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// 4 k-steps x 4 output blocks.  w points at chunk (group, nb=0) for this lane.
+__device__ __forceinline__ void mfma_group(const f32x4* __restrict__ w, const float (&b)[4], f32x16 (&acc)[4]) {
+    const f32x4 a0 = w[0], a1 = w[64], a2 = w[128], a3 = w[192];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        acc[0] = mfma(a0[e], b[e], acc[0]);
+        acc[1] = mfma(a1[e], b[e], acc[1]);
+        acc[2] = mfma(a2[e], b[e], acc[2]);
+        acc[3] = mfma(a3[e], b[e], acc[3]);
+    }
+}
+
+template <bool kAdd>
+__device__ __forceinline__ void bias_to_acc(const float* __restrict__ bperm, int h, f32x16 (&acc)[4]) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(bperm + h * 64);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = p[nb * 4 + q];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (kAdd) acc[nb][4 * q + c] = acc[nb][4 * q + c] + v[c];
+                else acc[nb][4 * q + c] = v[c];
+            }
+        }
+    }
+}
+
+// acc += W^T relu(in)   (Dense 128->128 on the pre-activated input, layers.py:285-288)
+__device__ __forceinline__ void dense128(const float* __restrict__ w, int lane, const f32x16 (&in)[4],
+                                         f32x16 (&acc)[4]) {
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(w) + lane;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float b[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[e] = fmaxf(in[kb][4 * t + e], 0.0f);
+            mfma_group(w4 + (kb * 4 + t) * 256, b, acc);
+        }
+    }
+}
+
+// x <- x + W2^T relu(W1^T relu(x) + b1) + b2    (ResNetMLPBlock.call, layers.py:284-298)
+__device__ __forceinline__ void resnet_block(const float* __restrict__ layer1, int lane, int h, f32x16 (&x)[4],
+                                             f32x16 (&hid)[4]) {
+    const float* layer2 = layer1 + kHiddenStride;
+    bias_to_acc<false>(layer1 + kHiddenWFloats, h, hid);
+    dense128(layer1, lane, x, hid);
+    bias_to_acc<true>(layer2 + kHiddenWFloats, h, x);
+    dense128(layer2, lane, hid, x);
+}
+
+__device__ __forceinline__ int stage_offset(int row, int chunk) {      // floats; XOR swizzle on 16-B chunks
+    return row * kStageRow + ((chunk ^ (row & 15)) << 2);
+}
+
+template <bool kMultiView>
+__global__ __launch_bounds__(256, kMultiView ? 1 : 2) void field_eval_kernel(FieldParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[kWavesPerWG * kTile * kStageRow];   // 64 KiB
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const long tile = (long)blockIdx.x * kWavesPerWG + wave;
+    if (tile >= p.n_tiles) return;                       // whole wave leaves; there are no barriers
+    float* stage = lds + wave * (kTile * kStageRow);
+
+    long g = tile * kTile + j;
+    const bool valid = g < p.total;
+    if (!valid) g = p.total - 1;
+    const int ray = (int)(g / p.S);                      // global ray index in [0, B*R)
+    const int sidx = (int)(g - (long)ray * p.S);
+    const int b = ray / p.R;
+
+    const float ox = p.rays_o[3 * ray + 0], oy = p.rays_o[3 * ray + 1], oz = p.rays_o[3 * ray + 2];
+    const float dx = p.rays_d[3 * ray + 0], dy = p.rays_d[3 * ray + 1], dz = p.rays_d[3 * ray + 2];
+    const float zz = p.z[g];
+    const float wx = ox + zz * dx, wy = oy + zz * dy, wz = oz + zz * dz;     // mul, then add (no FMA)
+
+    const float* __restrict__ net = p.net;
+    const f32x4* w0 = reinterpret_cast<const f32x4*>(net + kPackW0) + lane;
+
+    f32x16 x[4], hid[4];
+    f32x16 xsum[kMultiView ? 4 : 1];
+
+    for (int v = 0; v < p.V; ++v) {
+        const int bv = b * p.V + v;
+        const float* E = p.einv + 16 * bv;
+        const float* K = p.k4 + 16 * bv;
+        float cam[4], cdir[3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cam[r] = row_dot4(E, r, wx, wy, wz, 1.0f);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) cdir[r] = row_dot4(E, r, dx, dy, dz, 1.0f);      // Q3: w = 1
+        float pxl, pyl;
+        pixel_from_cam(K, cam, &pxl, &pyl);
+        const Taps tp = bilinear_taps(pxl, pyl, p.H, p.W);
+        const int tl = (bv * p.H + tp.y0) * p.W + tp.x0;
+        if (valid && h == 0) {
+            const long q = ((long)bv * p.R + (ray - b * p.R)) * p.S + sidx;
+            if (p.tap_idx) {
+                int4 t4 = make_int4(tl, tl + 1, tl + p.W, tl + p.W + 1);
+                *reinterpret_cast<int4*>(p.tap_idx + 4 * q) = t4;
+            }
+            if (p.pix) {
+                p.pix[2 * q + 0] = pxl;
+                p.pix[2 * q + 1] = pyl;
+            }
+        }
+
+        // ---- layer 0: Dense 379 -> 128 on [PE(cam xyz) | PE(cam dir) | 2*rgb-1 | features] ----
+        bias_to_acc<false>(net + kPackB0, h, x);
+#pragma unroll 1
+        for (int d = 0; d < 3; ++d) {
+            const float xin = h ? cdir[d] : cam[d];
+            float pe[20];
+#pragma unroll
+            for (int k = 0; k < kNFreq; ++k) {
+                const float arg = xin * (3.14159274101257324f * (float)(1 << k));   // fl32(pi)*2^k is exact
+                sincos_f32(arg, &pe[2 * k], &pe[2 * k + 1]);
+            }
+#pragma unroll
+            for (int gq = 0; gq < 5; ++gq) {
+                const float bb[4] = {pe[4 * gq], pe[4 * gq + 1], pe[4 * gq + 2], pe[4 * gq + 3]};
+                mfma_group(w0 + (kL0GroupPE + 5 * d + gq) * 256, bb, x);
+            }
+        }
+        {   // rgb taps of this lane's own sample, normalised 2*img-1 before the lerp (model_v0.py:120)
+            float bb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const float* img = p.images + 3 * (long)tl;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float a = img[c] * 2.0f - 1.0f, bq = img[3 + c] * 2.0f - 1.0f;
+                const float cq = img[3 * p.W + c] * 2.0f - 1.0f, dq = img[3 * p.W + 3 + c] * 2.0f - 1.0f;
+                const float val = bilerp(a, bq, cq, dq, tp.ax, tp.ay);
+                bb[c] = h ? 0.0f : val;
+            }
+            mfma_group(w0 + kL0GroupRGB * 256, bb, x);
+        }
+#pragma unroll 1
+        for (int hf = 0; hf < 2; ++hf) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // earlier reads of `stage` are done
+            const f32x4* fbase = reinterpret_cast<const f32x4*>(p.features) + hf * 32 + j;
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int src = 2 * it + h;                           // sample whose row this half-wave loads
+                const int tls = __shfl(tl, src);
+                const float axs = __shfl(tp.ax, src), ays = __shfl(tp.ay, src);
+                const f32x4* f = fbase + (long)tls * 64;
+                const f32x4 vtl = f[0], vtr = f[64], vbl = f[(long)p.W * 64], vbr = f[(long)p.W * 64 + 64];
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = bilerp(vtl[c], vtr[c], vbl[c], vbr[c], axs, ays);
+                *reinterpret_cast<f32x4*>(stage + stage_offset(src, j)) = o;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // writes landed (same-wave DS order)
+#pragma unroll
+            for (int gg = 0; gg < 16; ++gg) {
+                const f32x4 bv4 = *reinterpret_cast<const f32x4*>(stage + stage_offset(j, 2 * gg + h));
+                const float bb[4] = {bv4[0], bv4[1], bv4[2], bv4[3]};
+                mfma_group(w0 + (kL0GroupFeat + hf * 16 + gg) * 256, bb, x);
+            }
+        }
+
+        // ---- per-view feature blocks (layers.py:365-366) ----
+#pragma unroll 1
+        for (int bi = 0; bi < 3; ++bi) resnet_block(net + kPackHidden + (2 * bi) * kHiddenStride, lane, h, x, hid);
+
+        if (kMultiView) {                                             // reduce_mean over views (layers.py:368-370)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) xsum[nb] = (v == 0) ? x[nb] : xsum[nb] + x[nb];
+        }
+    }
+    if (kMultiView) {
+        const float nv = (float)p.V;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) x[nb] = xsum[nb] / nv;
+    }
+
+    // ---- fusion blocks (layers.py:373-374) ----
+#pragma unroll 1
+    for (int bi = 3; bi < 6; ++bi) resnet_block(net + kPackHidden + (2 * bi) * kHiddenStride, lane, h, x, hid);
+
+    // ---- read-out: Dense 128 -> 4 on relu(x), sigmoid / softplus (layers.py:392-397) ----
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = (r < 4) ? net[kPackBr + r] : 0.0f;
+    const f32x4* wr = reinterpret_cast<const f32x4*>(net + kPackWr) + lane;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 a = wr[(kb * 4 + t) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o = mfma(a[e], fmaxf(x[kb][4 * t + e], 0.0f), o);
+        }
+    }
+    if (valid && h == 0) {
+        f32x4 out;
+        out[0] = sigmoid_f32(o[0]);
+        out[1] = sigmoid_f32(o[1]);
+        out[2] = sigmoid_f32(o[2]);
+        out[3] = softplus_f32(o[3]);
+        *reinterpret_cast<f32x4*>(p.rgbs + 4 * g) = out;
+    }
+}
+
+// ---- weight packing -------------------------------------------------------------------------
+__global__ void pack_net_kernel(const float* __restrict__ src, float* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kPackTotal) return;
+    float val = 0.0f;
+    auto lane_parts = [](int rem, int& nb_or_zero, int& i, int& h, int& e) {
+        nb_or_zero = rem / 256;
+        const int lane = (rem % 256) / 4;
+        e = rem % 4;
+        i = lane & 31;
+        h = lane >> 5;
+    };
+    if (idx < kPackB0) {                                              // layer-0 kernel
+        const int G = idx / 1024;
+        int nb, i, h, e;
+        lane_parts(idx % 1024, nb, i, h, e);
+        int row = -1;
+        if (G < kL0GroupRGB) row = (h ? 60 : 0) + 4 * G + e;
+        else if (G == kL0GroupRGB) row = (h == 0 && e < 3) ? 120 + e : -1;
+        else {
+            const int q = G - kL0GroupFeat;
+            row = 123 + 128 * (q / 16) + 8 * (q % 16) + 4 * h + e;
+        }
+        if (row >= 0) val = src[kKerasW0 + row * kHidden + 32 * nb + i];
+    } else if (idx < kPackHidden) {                                   // layer-0 bias, [h][nb][r]
+        const int q = idx - kPackB0;
+        val = src[kKerasB0 + 32 * ((q % 64) / 16) + acc_row(q % 16, q / 64)];
+    } else if (idx < kPackWr) {                                       // 12 hidden Dense layers
+        const int q = idx - kPackHidden;
+        const int layer = q / kHiddenStride, r = q % kHiddenStride;
+        const int wsrc = kKerasBlocks + (layer / 2) * kKerasBlockStride + (layer % 2) * (kHidden * kHidden + kHidden);
+        if (r < kHiddenWFloats) {
+            const int chunk = r / 256;
+            int dummy, i, h, e;
+            lane_parts(r % 256, dummy, i, h, e);
+            const int kb = chunk / 16, t = (chunk / 4) % 4, nb = chunk % 4;
+            val = src[wsrc + (32 * kb + 8 * t + 4 * h + e) * kHidden + 32 * nb + i];
+        } else {
+            const int qq = r - kHiddenWFloats;
+            val = src[wsrc + kHidden * kHidden + 32 * ((qq % 64) / 16) + acc_row(qq % 16, qq / 64)];
+        }
+    } else if (idx < kPackBr) {                                       // read-out kernel, rows >= 4 zero
+        const int q = idx - kPackWr;
+        const int chunk = q / 256;
+        int dummy, i, h, e;
+        lane_parts(q % 256, dummy, i, h, e);
+        const int kb = chunk / 4, t = chunk % 4;
+        if (i < 4) val = src[kKerasWr + (32 * kb + 8 * t + 4 * h + e) * 4 + i];
+    } else if (idx < kPackBr + 4) {
+        val = src[kKerasBr + (idx - kPackBr)];
+    }
+    dst[idx] = val;
+}
+
+hipError_t launch_pack_net(const float* net_keras, float* packed, hipStream_t stream) {
+    const int threads = 256;
+    hipLaunchKernelGGL(pack_net_kernel, dim3((kPackTotal + threads - 1) / threads), dim3(threads), 0, stream,
+                       net_keras, packed);
+    return hipGetLastError();
+}
+
+hipError_t launch_field_eval(const FieldParams& p, hipStream_t stream) {
+    const long wgs = (p.n_tiles + kWavesPerWG - 1) / kWavesPerWG;
+    if (p.V > 1)
+        hipLaunchKernelGGL(field_eval_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(field_eval_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace mvnerf
