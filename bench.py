@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Benchmark of the MVNeRF render hot path on MI355X (BASELINE.json metric: rendered rays/sec).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full `_call` (model_v0.py:113-184) over one batch of synthetic rays: stratified
+depths -> coarse field (64 samples/ray) -> composite -> resample -> fine field (128 samples/ray) ->
+composite.  Workload at every N: BASELINE.json configs[1] as restated in SURVEY.md 8d (cfg2):
+B=1 scene, V=1 source view of 64x64 (3+256 channels), R=4096 rays (every pixel of a 64x64 target
+view), fp32, inputs resident in HBM before the timed region.  N>1: every rank renders its own
+scene (rays/scenes are independent units, no data-path collective) -> weak scaling.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (field_eval_kernel, fp32
+MFMA bound): algorithmic FLOPs per launch (491 264 FLOP/sample) / its average
+duration measured with HIP events inside the timed region, against the 157.3 TFLOP/s fp32 MFMA
+peak.  `cpu_baseline` times the NumPy oracle (a port of the reference's TF graph; the reference
+itself cannot run here) on a bounded sample of the same rays on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from thesis_clip_nerf_amd import ops  # noqa: E402
+from thesis_clip_nerf_amd.synthetic import make_scene  # noqa: E402
+
+FLOP_PER_SAMPLE_V1 = 491264          # BASELINE.md 3 (2 x 245 632 MAC), one source view
+PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md, chip-level parameters
+
+
+def flop_per_sample(v):
+    return 2 * (v * (379 * 128 + 6 * 128 * 128) + 6 * 128 * 128 + 128 * 4)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--views', type=int, default=1)
+    ap.add_argument('--size', type=int, default=64, help='source/target image side (rays = size^2)')
+    ap.add_argument('--cpu-rays', type=int, default=512, help='rays of the bounded CPU-baseline sample (0 = skip)')
+    ap.add_argument('--fused-call', action='store_true', help='time mvnerf_render_fwd (one C call) instead of the op sequence')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sc = make_scene(seed=rank, batch=1, n_views=args.views, height=args.size, width=args.size)
+    t = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in
+         ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'u_coarse', 'u_fine', 'coarse', 'fine']}
+    pc, pf = ops.pack_net(t['coarse']), ops.pack_net(t['fine'])
+    b, r, s = t['u_coarse'].shape
+    ws = torch.empty(ops.render_workspace_bytes(b, r, s), dtype=torch.uint8, device=dev)
+    near, far = sc['near'], sc['far']
+    field_args = (t['images'], t['features'], t['intrinsics'], t['extrinsics_inv'])
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+
+    def step_ops(e=None):
+        z = ops.stratified_depths(t['u_coarse'], near, far)
+        if e: e[0].record()
+        rgbs_c = ops.field_eval(t['rays_o'], t['rays_d'], z, *field_args, pc)
+        if e: e[1].record()
+        rgb, depth, w = ops.composite(z, rgbs_c)
+        z_all = ops.resample(z, w, t['u_fine'])
+        if e: e[2].record()
+        rgbs_f = ops.field_eval(t['rays_o'], t['rays_d'], z_all, *field_args, pf)
+        if e: e[3].record()
+        fine_rgb, fine_depth, _ = ops.composite(z_all, rgbs_f, return_weights=False)
+        return rgb, depth, fine_rgb, fine_depth
+
+    def step_fused(e=None):
+        return ops.render_fwd(t['rays_o'], t['rays_d'], *field_args, pc, pf, t['u_coarse'], t['u_fine'], near, far,
+                              workspace=ws)
+
+    step = step_fused if args.fused_call else step_ops
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(ev[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    rays_per_step = b * r * world
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = rays_per_step * args.steps / elapsed
+
+    result = {
+        'metric': 'rendered_rays_per_sec', 'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'cfg2: _call on B=1 scene/GPU, V={args.views} source view {args.size}x{args.size}x(3+256) fp32, '
+                               f'R={r} rays (all pixels of a {args.size}x{args.size} target), 64 coarse + 128 fine samples/ray, '
+                               'two 247300-param ResNet-MLPs (379->128, 3+3 blocks), explicit uniforms',
+                   'rays_per_gpu': b * r, 'samples_per_ray': [s, 2 * s], 'n_views': args.views,
+                   'call': 'mvnerf_render_fwd' if args.fused_call else 'op sequence (6 C-ABI launches/step)',
+                   'parallelism': f'ray/scene sharding x{world}, no data-path collective'},
+    }
+
+    if rank == 0:
+        fps = flop_per_sample(args.views)
+        if not args.fused_call:
+            coarse_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+            fine_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+            flops_c, flops_f = fps * b * r * s, fps * b * r * 2 * s
+            # the fine-pass launch is the dominant kernel instance (2/3 of the FLOPs)
+            achieved = flops_f / (fine_ms * 1e-3) / 1e12
+            result['roofline'] = {
+                'bound': 'mfma', 'kernel': 'field_eval_kernel<false> (fine pass, S=128)' if args.views == 1 else 'field_eval_kernel<true> (fine pass, S=128)',
+                'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+                'traffic': None, 'flop_per_launch': flops_f, 'avg_launch_ms': fine_ms,
+                'coarse_launch': {'flop_per_launch': flops_c, 'avg_launch_ms': coarse_ms,
+                                  'achieved': flops_c / (coarse_ms * 1e-3) / 1e12},
+                'field_kernel_share_of_step': (coarse_ms + fine_ms) / ms_per_step,
+            }
+            pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+            if os.path.exists(pmc):
+                try:
+                    result['roofline']['traffic'] = json.load(open(pmc)).get('field_eval_fine_hbm_bytes_per_launch')
+                except Exception:
+                    pass
+        if world == 1 and args.cpu_rays > 0:
+            result['cpu_baseline'], result['parity'] = cpu_baseline(sc, out, args.cpu_rays)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sc, gpu_out, n_rays):
+    """Oracle (oracle/mvnerf_oracle.py, NumPy fp32 port of the TF graph) on the first `n_rays` rays of
+    the benchmark scene, on this box's host cores; also the checker for the GPU result on those rays."""
+    from oracle import mvnerf_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        blas_threads = os.cpu_count()
+    cn, fn = O.unflatten_net(sc['coarse']), O.unflatten_net(sc['fine'])
+    sl = slice(0, n_rays)
+
+    def run():
+        return O.render_call(cn, fn, sc['rays_o'][:, sl], sc['rays_d'][:, sl], sc['images'], sc['intrinsics'],
+                             sc['extrinsics_inv'], sc['features'], sc['near'], sc['far'], sc['n_samples'],
+                             sc['u_coarse'][:, sl], sc['u_fine'][:, sl])
+    run()                                   # warm-up (BLAS thread pool, page faults)
+    times = []
+    ref = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ref = run()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    base = {'value': n_rays / med, 'unit': 'rays/s', 'cores': int(blas_threads), 'kind': 'port',
+            'sample': f'first {n_rays} of the 4096 rays of the same scene, full 64+128 samples, NumPy fp32 oracle '
+                      f'(op-for-op port of the TF graph; BLAS sgemm uses {blas_threads} threads, the rest is single-threaded), '
+                      f'median of 3 after 1 warm-up, {med:.2f} s per run; host has {os.cpu_count()} logical cores'}
+    names = ['rgb', 'depth', 'fine_rgb', 'fine_depth']
+    parity = {}
+    for n, g, rf in zip(names, gpu_out, ref):
+        diff = np.abs(g.cpu().numpy()[:, sl] - rf)
+        parity[n + '_max_abs'] = float(diff.max())
+        parity[n + '_mean_l1'] = float(diff.mean())
+    parity['checked_rays'] = n_rays
+    parity['tolerance'] = 1e-4
+    return base, parity
+
+
+if __name__ == '__main__':
+    main()
