@@ -1,16 +1,17 @@
 // Fused radiance-field evaluation for gfx950 (MI355X):
 //   project -> bilinear gather -> positional encoding -> ResNet-MLP trunk -> read-out
 // for 32 samples per wavefront, activations resident in the register file, weights streamed from
-// L2 in MFMA operand order (mvnerf_pack.h), gathered features transposed through LDS.
+// L2 in MFMA operand order (mvnerf_pack.h) one 4 KiB step ahead of use, gathered features
+// transposed through wave-private LDS.
 //
 // Reference being replaced: model_v0.py:122-144 / :157-180 (see include/mvnerf_hip.h,
 // mvnerf_field_eval).  One launch evaluates B*R*S samples; a wavefront owns 32 consecutive samples
 // (half a coarse ray, a quarter of a fine ray), waves are independent (no workgroup barrier).
 #include <hip/hip_runtime.h>
 
+#include "mvnerf_kernels.h"
 #include "mvnerf_math.h"
 #include "mvnerf_pack.h"
-#include "mvnerf_kernels.h"
 
 namespace mvnerf {
 
@@ -25,16 +26,38 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// 4 k-steps x 4 output blocks.  w points at chunk (group, nb=0) for this lane.
-__device__ __forceinline__ void mfma_group(const f32x4* __restrict__ w, const float (&b)[4], f32x16 (&acc)[4]) {
-    const f32x4 a0 = w[0], a1 = w[64], a2 = w[128], a3 = w[192];
+// The weight stream: `cur` holds the 4 chunks (4 KiB per wave) of the step being consumed, `next`
+// points at this lane's 16 bytes of the following step.  Every step first issues the loads of the
+// following step, then runs its 16 MFMAs (1024 cycles of matrix pipe), so an L2 round trip is
+// always covered, also across layer boundaries (the chunks of all layers are contiguous).
+struct WStream {
+    const f32x4* next;
+    f32x4 cur[4];
+};
+
+__device__ __forceinline__ void ws_begin(WStream& ws, const f32x4* first) {
+    ws.cur[0] = first[0];
+    ws.cur[1] = first[64];
+    ws.cur[2] = first[128];
+    ws.cur[3] = first[192];
+    ws.next = first + 256;
+}
+
+// One step = 4 k-steps x 4 output blocks: acc[nb] += A(cur[nb])[e] x b[e]
+__device__ __forceinline__ void mfma_step(WStream& ws, const float (&b)[4], f32x16 (&acc)[4]) {
+    const f32x4 n0 = ws.next[0], n1 = ws.next[64], n2 = ws.next[128], n3 = ws.next[192];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        acc[0] = mfma(a0[e], b[e], acc[0]);
-        acc[1] = mfma(a1[e], b[e], acc[1]);
-        acc[2] = mfma(a2[e], b[e], acc[2]);
-        acc[3] = mfma(a3[e], b[e], acc[3]);
+        acc[0] = mfma(ws.cur[0][e], b[e], acc[0]);
+        acc[1] = mfma(ws.cur[1][e], b[e], acc[1]);
+        acc[2] = mfma(ws.cur[2][e], b[e], acc[2]);
+        acc[3] = mfma(ws.cur[3][e], b[e], acc[3]);
     }
+    ws.cur[0] = n0;
+    ws.cur[1] = n1;
+    ws.cur[2] = n2;
+    ws.cur[3] = n3;
+    ws.next += 256;
 }
 
 template <bool kAdd>
@@ -55,9 +78,7 @@ __device__ __forceinline__ void bias_to_acc(const float* __restrict__ bperm, int
 }
 
 // acc += W^T relu(in)   (Dense 128->128 on the pre-activated input, layers.py:285-288)
-__device__ __forceinline__ void dense128(const float* __restrict__ w, int lane, const f32x16 (&in)[4],
-                                         f32x16 (&acc)[4]) {
-    const f32x4* w4 = reinterpret_cast<const f32x4*>(w) + lane;
+__device__ __forceinline__ void dense128(WStream& ws, const f32x16 (&in)[4], f32x16 (&acc)[4]) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
@@ -65,19 +86,18 @@ __device__ __forceinline__ void dense128(const float* __restrict__ w, int lane, 
             float b[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) b[e] = fmaxf(in[kb][4 * t + e], 0.0f);
-            mfma_group(w4 + (kb * 4 + t) * 256, b, acc);
+            mfma_step(ws, b, acc);
         }
     }
 }
 
 // x <- x + W2^T relu(W1^T relu(x) + b1) + b2    (ResNetMLPBlock.call, layers.py:284-298)
-__device__ __forceinline__ void resnet_block(const float* __restrict__ layer1, int lane, int h, f32x16 (&x)[4],
+__device__ __forceinline__ void resnet_block(WStream& ws, const float* __restrict__ bias1, int h, f32x16 (&x)[4],
                                              f32x16 (&hid)[4]) {
-    const float* layer2 = layer1 + kHiddenStride;
-    bias_to_acc<false>(layer1 + kHiddenWFloats, h, hid);
-    dense128(layer1, lane, x, hid);
-    bias_to_acc<true>(layer2 + kHiddenWFloats, h, x);
-    dense128(layer2, lane, hid, x);
+    bias_to_acc<false>(bias1, h, hid);
+    dense128(ws, x, hid);
+    bias_to_acc<true>(bias1 + 128, h, x);
+    dense128(ws, hid, x);
 }
 
 __device__ __forceinline__ int stage_offset(int row, int chunk) {      // floats; XOR swizzle on 16-B chunks
@@ -109,20 +129,24 @@ __global__ __launch_bounds__(256, kMultiView ? 1 : 2) void field_eval_kernel(Fie
     const float wx = ox + zz * dx, wy = oy + zz * dy, wz = oz + zz * dz;     // mul, then add (no FMA)
 
     const float* __restrict__ net = p.net;
-    const f32x4* w0 = reinterpret_cast<const f32x4*>(net + kPackW0) + lane;
+    const f32x4* wbase = reinterpret_cast<const f32x4*>(net) + lane;
 
     f32x16 x[4], hid[4];
     f32x16 xsum[kMultiView ? 4 : 1];
+    WStream ws;
 
     for (int v = 0; v < p.V; ++v) {
+        ws_begin(ws, wbase);                             // layer-0 group 0 (re-read per view)
         const int bv = b * p.V + v;
         const float* E = p.einv + 16 * bv;
         const float* K = p.k4 + 16 * bv;
-        float cam[4], cdir[3];
+        float cam[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) cam[r] = row_dot4(E, r, wx, wy, wz, 1.0f);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) cdir[r] = row_dot4(E, r, dx, dy, dz, 1.0f);      // Q3: w = 1
+        // PE inputs of this lane: lower half-wave encodes cam xyz, upper half cam dir (Q3: w = 1)
+        const float in0 = h ? row_dot4(E, 0, dx, dy, dz, 1.0f) : cam[0];
+        const float in1 = h ? row_dot4(E, 1, dx, dy, dz, 1.0f) : cam[1];
+        const float in2 = h ? row_dot4(E, 2, dx, dy, dz, 1.0f) : cam[2];
         float pxl, pyl;
         pixel_from_cam(K, cam, &pxl, &pyl);
         const Taps tp = bilinear_taps(pxl, pyl, p.H, p.W);
@@ -143,7 +167,7 @@ __global__ __launch_bounds__(256, kMultiView ? 1 : 2) void field_eval_kernel(Fie
         bias_to_acc<false>(net + kPackB0, h, x);
 #pragma unroll 1
         for (int d = 0; d < 3; ++d) {
-            const float xin = h ? cdir[d] : cam[d];
+            const float xin = d == 0 ? in0 : (d == 1 ? in1 : in2);
             float pe[20];
 #pragma unroll
             for (int k = 0; k < kNFreq; ++k) {
@@ -153,7 +177,7 @@ __global__ __launch_bounds__(256, kMultiView ? 1 : 2) void field_eval_kernel(Fie
 #pragma unroll
             for (int gq = 0; gq < 5; ++gq) {
                 const float bb[4] = {pe[4 * gq], pe[4 * gq + 1], pe[4 * gq + 2], pe[4 * gq + 3]};
-                mfma_group(w0 + (kL0GroupPE + 5 * d + gq) * 256, bb, x);
+                mfma_step(ws, bb, x);
             }
         }
         {   // rgb taps of this lane's own sample, normalised 2*img-1 before the lerp (model_v0.py:120)
@@ -166,7 +190,7 @@ __global__ __launch_bounds__(256, kMultiView ? 1 : 2) void field_eval_kernel(Fie
                 const float val = bilerp(a, bq, cq, dq, tp.ax, tp.ay);
                 bb[c] = h ? 0.0f : val;
             }
-            mfma_group(w0 + kL0GroupRGB * 256, bb, x);
+            mfma_step(ws, bb, x);
         }
 #pragma unroll 1
         for (int hf = 0; hf < 2; ++hf) {
@@ -189,13 +213,13 @@ __global__ __launch_bounds__(256, kMultiView ? 1 : 2) void field_eval_kernel(Fie
             for (int gg = 0; gg < 16; ++gg) {
                 const f32x4 bv4 = *reinterpret_cast<const f32x4*>(stage + stage_offset(j, 2 * gg + h));
                 const float bb[4] = {bv4[0], bv4[1], bv4[2], bv4[3]};
-                mfma_group(w0 + (kL0GroupFeat + hf * 16 + gg) * 256, bb, x);
+                mfma_step(ws, bb, x);
             }
         }
 
         // ---- per-view feature blocks (layers.py:365-366) ----
 #pragma unroll 1
-        for (int bi = 0; bi < 3; ++bi) resnet_block(net + kPackHidden + (2 * bi) * kHiddenStride, lane, h, x, hid);
+        for (int bi = 0; bi < 3; ++bi) resnet_block(ws, net + kPackBHidden + 256 * bi, h, x, hid);
 
         if (kMultiView) {                                             // reduce_mean over views (layers.py:368-370)
 #pragma unroll
@@ -208,22 +232,31 @@ __global__ __launch_bounds__(256, kMultiView ? 1 : 2) void field_eval_kernel(Fie
         for (int nb = 0; nb < 4; ++nb) x[nb] = xsum[nb] / nv;
     }
 
-    // ---- fusion blocks (layers.py:373-374) ----
+    // ---- fusion blocks (layers.py:373-374); the stream continues into hidden layer 6 ----
 #pragma unroll 1
-    for (int bi = 3; bi < 6; ++bi) resnet_block(net + kPackHidden + (2 * bi) * kHiddenStride, lane, h, x, hid);
+    for (int bi = 3; bi < 6; ++bi) resnet_block(ws, net + kPackBHidden + 256 * bi, h, x, hid);
 
     // ---- read-out: Dense 128 -> 4 on relu(x), sigmoid / softplus (layers.py:392-397) ----
+    // the stream now holds read-out chunks (kb, t = 0..3); rows 0..3 of the 32-row tile are real
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = (r < 4) ? net[kPackBr + r] : 0.0f;
-    const f32x4* wr = reinterpret_cast<const f32x4*>(net + kPackWr) + lane;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
+        f32x4 n[4];
+        if (kb < 3) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) n[t] = ws.next[64 * t];
+            ws.next += 256;
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const f32x4 a = wr[(kb * 4 + t) * 64];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o = mfma(a[e], fmaxf(x[kb][4 * t + e], 0.0f), o);
+            for (int e = 0; e < 4; ++e) o = mfma(ws.cur[t][e], fmaxf(x[kb][4 * t + e], 0.0f), o);
+        }
+        if (kb < 3) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ws.cur[t] = n[t];
         }
     }
     if (valid && h == 0) {
@@ -241,17 +274,10 @@ __global__ void pack_net_kernel(const float* __restrict__ src, float* __restrict
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= kPackTotal) return;
     float val = 0.0f;
-    auto lane_parts = [](int rem, int& nb_or_zero, int& i, int& h, int& e) {
-        nb_or_zero = rem / 256;
-        const int lane = (rem % 256) / 4;
-        e = rem % 4;
-        i = lane & 31;
-        h = lane >> 5;
-    };
-    if (idx < kPackB0) {                                              // layer-0 kernel
-        const int G = idx / 1024;
-        int nb, i, h, e;
-        lane_parts(idx % 1024, nb, i, h, e);
+    // position inside a 1 KiB chunk: [lane][e]
+    const int e = idx % 4, lane = (idx % kChunkFloats) / 4, i = lane & 31, h = lane >> 5;
+    if (idx < kPackHidden) {                                          // layer-0 kernel
+        const int G = idx / kGroupFloats, nb = (idx % kGroupFloats) / kChunkFloats;
         int row = -1;
         if (G < kL0GroupRGB) row = (h ? 60 : 0) + 4 * G + e;
         else if (G == kL0GroupRGB) row = (h == 0 && e < 3) ? 120 + e : -1;
@@ -260,30 +286,27 @@ __global__ void pack_net_kernel(const float* __restrict__ src, float* __restrict
             row = 123 + 128 * (q / 16) + 8 * (q % 16) + 4 * h + e;
         }
         if (row >= 0) val = src[kKerasW0 + row * kHidden + 32 * nb + i];
-    } else if (idx < kPackHidden) {                                   // layer-0 bias, [h][nb][r]
-        const int q = idx - kPackB0;
-        val = src[kKerasB0 + 32 * ((q % 64) / 16) + acc_row(q % 16, q / 64)];
-    } else if (idx < kPackWr) {                                       // 12 hidden Dense layers
+    } else if (idx < kPackWr) {                                       // 12 hidden Dense kernels
         const int q = idx - kPackHidden;
-        const int layer = q / kHiddenStride, r = q % kHiddenStride;
+        const int layer = q / kHiddenWFloats, r = q % kHiddenWFloats;
         const int wsrc = kKerasBlocks + (layer / 2) * kKerasBlockStride + (layer % 2) * (kHidden * kHidden + kHidden);
-        if (r < kHiddenWFloats) {
-            const int chunk = r / 256;
-            int dummy, i, h, e;
-            lane_parts(r % 256, dummy, i, h, e);
-            const int kb = chunk / 16, t = (chunk / 4) % 4, nb = chunk % 4;
-            val = src[wsrc + (32 * kb + 8 * t + 4 * h + e) * kHidden + 32 * nb + i];
-        } else {
-            const int qq = r - kHiddenWFloats;
-            val = src[wsrc + kHidden * kHidden + 32 * ((qq % 64) / 16) + acc_row(qq % 16, qq / 64)];
-        }
-    } else if (idx < kPackBr) {                                       // read-out kernel, rows >= 4 zero
-        const int q = idx - kPackWr;
-        const int chunk = q / 256;
-        int dummy, i, h, e;
-        lane_parts(q % 256, dummy, i, h, e);
+        const int grp = r / kGroupFloats, nb = (r % kGroupFloats) / kChunkFloats;
+        const int kb = grp / 4, t = grp % 4;
+        val = src[wsrc + (32 * kb + 8 * t + 4 * h + e) * kHidden + 32 * nb + i];
+    } else if (idx < kPackB0) {                                       // read-out kernel, rows >= 4 zero
+        const int chunk = (idx - kPackWr) / kChunkFloats;
         const int kb = chunk / 4, t = chunk % 4;
         if (i < 4) val = src[kKerasWr + (32 * kb + 8 * t + 4 * h + e) * 4 + i];
+    } else if (idx < kPackBr) {                                       // biases, [h][nb][r] per layer
+        const int q = idx - kPackB0;
+        const int layer = q / 128, qq = q % 128;                      // 0 = layer 0, 1..12 = hidden
+        const int feat = 32 * ((qq % 64) / 16) + acc_row(qq % 16, qq / 64);
+        if (layer == 0) val = src[kKerasB0 + feat];
+        else {
+            const int l = layer - 1;
+            val = src[kKerasBlocks + (l / 2) * kKerasBlockStride + (l % 2) * (kHidden * kHidden + kHidden) +
+                      kHidden * kHidden + feat];
+        }
     } else if (idx < kPackBr + 4) {
         val = src[kKerasBr + (idx - kPackBr)];
     }

@@ -58,10 +58,21 @@ MV_HD void sincos_reduced(float r, int q, float* s_out, float* c_out) {
     *c_out = c;
 }
 
+// |x| >= 1e5 (camera-space coordinates beyond ~60 m at the top octave) and non-finite x: two-term
+// Cody-Waite in float64.  Accurate to ~1e-7 up to |x| ~ 1e9; beyond that the fp32 argument spacing
+// exceeds 2*pi and the value is numerically meaningless in the reference as well.
+MV_HD void sincos_large(float x, float* s_out, float* c_out) {
+    const double xd = (double)x;
+    const double j = rint(xd * 0.63661977236758134308);
+    double r = fma(j, -1.57079632679489655800e+00, xd);
+    r = fma(j, -6.12323399573676603587e-17, r);
+    const double jq = j - 4.0 * floor(j * 0.25);          // j mod 4, exact while |j| < 2^53
+    sincos_reduced((float)r, (int)jq, s_out, c_out);
+}
+
 MV_HD void sincos_f32(float x, float* s_out, float* c_out) {
-    if (!(fabsf(x) < 100000.0f)) {          // also catches NaN/Inf: defer to libm / ocml
-        *s_out = sinf(x);
-        *c_out = cosf(x);
+    if (!(fabsf(x) < 100000.0f)) {
+        sincos_large(x, s_out, c_out);
         return;
     }
     const float j = rintf(x * 0.636619747f);

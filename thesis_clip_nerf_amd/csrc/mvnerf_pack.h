@@ -14,21 +14,28 @@
 namespace mvnerf {
 
 constexpr int kChunkFloats = 256;                       // 64 lanes x 4 floats = 1 KiB
-// layer 0: 15 PE groups (h=0: xyz rows 0..59, h=1: dir rows 60..119), 1 rgb group, 32 feature groups
+// The kernel consumes the chunks strictly in storage order ("weight stream"), four chunks (one
+// group x 4 output blocks, 4 KiB) per step, prefetching one step ahead across layer boundaries:
+//   layer 0   : 48 groups x 4 nb   (15 PE groups [h=0: xyz rows 0..59, h=1: dir rows 60..119],
+//                                   1 rgb group, 32 feature groups)
+//   12 hidden : 16 groups x 4 nb each, group = (kb, t)
+//   read-out  : 16 chunks (kb, t), output rows i >= 4 zero; consumed 4 chunks per step
+// followed by the biases in accumulator order [h][nb][r].
 constexpr int kL0Groups = 48;
 constexpr int kL0GroupPE = 0;
 constexpr int kL0GroupRGB = 15;
 constexpr int kL0GroupFeat = 16;
+constexpr int kGroupFloats = 4 * kChunkFloats;                         // 1024
 constexpr int kPackW0 = 0;
-constexpr int kPackW0Floats = kL0Groups * 4 * kChunkFloats;            // 49152
-constexpr int kPackB0 = kPackW0 + kPackW0Floats;                       // bias perm [h][nb][r], 128
-constexpr int kPackHidden = kPackB0 + 128;                             // 49280
-constexpr int kHiddenWFloats = 16 * 4 * kChunkFloats;                  // 16384: [kb][t][nb] chunks
-constexpr int kHiddenStride = kHiddenWFloats + 128;                    // + bias perm
+constexpr int kPackW0Floats = kL0Groups * kGroupFloats;                // 49152
+constexpr int kPackHidden = kPackW0 + kPackW0Floats;                   // 49152
+constexpr int kHiddenWFloats = 16 * kGroupFloats;                      // 16384
 constexpr int kNumHidden = 12;                                         // 6 blocks x 2 Dense
-constexpr int kPackWr = kPackHidden + kNumHidden * kHiddenStride;      // 247424: [kb][t] chunks, rows i>=4 zero
+constexpr int kPackWr = kPackHidden + kNumHidden * kHiddenWFloats;     // 245760
 constexpr int kPackWrFloats = 16 * kChunkFloats;                       // 4096
-constexpr int kPackBr = kPackWr + kPackWrFloats;                       // 251520
+constexpr int kPackB0 = kPackWr + kPackWrFloats;                       // 249856: bias perm [h][nb][r], 128
+constexpr int kPackBHidden = kPackB0 + 128;                            // 12 x 128
+constexpr int kPackBr = kPackBHidden + kNumHidden * 128;               // 251520
 constexpr int kPackTotal = kPackBr + 8;                                // 251528 (padded to 16 B multiple)
 
 // feature index held by accumulator register r of lane-half h inside a 32-wide block
