@@ -11,7 +11,7 @@ import os
 from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libmvnerf_hip.so')
+LIB_PATH = os.environ.get('MVNERF_LIB', os.path.join(_HERE, 'lib', 'libmvnerf_hip.so'))   # override: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'mvnerf_hip.h')
 
 NET_PARAMS = 247300

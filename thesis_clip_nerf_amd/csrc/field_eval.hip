@@ -9,6 +9,9 @@
 // (half a coarse ray, a quarter of a fine ray), waves are independent (no workgroup barrier).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "mvnerf_kernels.h"
 #include "mvnerf_math.h"
 #include "mvnerf_pack.h"
@@ -19,12 +22,45 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kTile = 32;            // samples per wavefront (MFMA N dimension)
-constexpr int kWavesPerWG = 4;
+// Persistent workgroups, one per CU.  Single-view: 8 waves = 2 per SIMD, where the first four run at
+// raised priority: each SIMD's matrix pipe then always serves one wave at full rate and its partner
+// fills the gaps left by that wave's gather / sin-cos / wait phases, instead of the two identical
+// instruction streams running in lock-step and stalling together.  Tiles are handed out through an
+// atomic counter (zeroed by the launcher before every launch), so the uneven progress balances out.
 constexpr int kStageRow = 128;       // floats per staged sample row (half of the 256 channels)
+
+// Tuning switches (A/B-tested on the GPU, see DESIGN.md "Field kernel: what was measured")
+#ifndef MV_PERSIST
+#define MV_PERSIST 1       // 1: one workgroup per CU pulling tiles from an atomic ticket; 0: one tile per wave
+#endif
+#ifndef MV_PRIO
+#define MV_PRIO 1          // raise the priority of waves 0..3 of an 8-wave workgroup
+#endif
+#ifndef MV_ABL_PE
+#define MV_ABL_PE 0        // timing-only ablations (wrong results): skip sin/cos
+#endif
+#ifndef MV_ABL_GATHER
+#define MV_ABL_GATHER 0    // skip feature gather + lerp + LDS staging
+#endif
+#ifndef MV_ABL_BIAS
+#define MV_ABL_BIAS 0      // skip bias loads
+#endif
+#ifndef MV_ABL_WLOAD
+#define MV_ABL_WLOAD 0     // do not stream weights (re-use the first 4 chunks)
+#endif
+#ifndef MV_PIN_LOADS
+#define MV_PIN_LOADS 1
+#endif
+#ifndef MV_WAVES
+#define MV_WAVES 8         // waves per workgroup of the single-view kernel (4 or 8)
+#endif
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+
+// relu as one v_med3_f32 (fmaxf lowers to a canonicalising v_max pair in front of every MFMA)
+__device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
 
 // The weight stream: `cur` holds the 4 chunks (4 KiB per wave) of the step being consumed, `next`
 // points at this lane's 16 bytes of the following step.  Every step first issues the loads of the
@@ -45,7 +81,14 @@ __device__ __forceinline__ void ws_begin(WStream& ws, const f32x4* first) {
 
 // One step = 4 k-steps x 4 output blocks: acc[nb] += A(cur[nb])[e] x b[e]
 __device__ __forceinline__ void mfma_step(WStream& ws, const float (&b)[4], f32x16 (&acc)[4]) {
+#if MV_ABL_WLOAD
+    const f32x4 n0 = ws.cur[1], n1 = ws.cur[2], n2 = ws.cur[3], n3 = ws.cur[0];
+#else
     const f32x4 n0 = ws.next[0], n1 = ws.next[64], n2 = ws.next[128], n3 = ws.next[192];
+#endif
+#if MV_PIN_LOADS
+    __builtin_amdgcn_sched_barrier(0);      // keep the prefetch a full step ahead of its use
+#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         acc[0] = mfma(ws.cur[0][e], b[e], acc[0]);
@@ -62,6 +105,15 @@ __device__ __forceinline__ void mfma_step(WStream& ws, const float (&b)[4], f32x
 
 template <bool kAdd>
 __device__ __forceinline__ void bias_to_acc(const float* __restrict__ bperm, int h, f32x16 (&acc)[4]) {
+#if MV_ABL_BIAS
+    if (!kAdd) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = (float)h;
+    }
+    return;
+#endif
     const f32x4* p = reinterpret_cast<const f32x4*>(bperm + h * 64);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
@@ -85,7 +137,7 @@ __device__ __forceinline__ void dense128(WStream& ws, const f32x16 (&in)[4], f32
         for (int t = 0; t < 4; ++t) {
             float b[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) b[e] = fmaxf(in[kb][4 * t + e], 0.0f);
+            for (int e = 0; e < 4; ++e) b[e] = relu(in[kb][4 * t + e]);
             mfma_step(ws, b, acc);
         }
     }
@@ -105,16 +157,25 @@ __device__ __forceinline__ int stage_offset(int row, int chunk) {      // floats
 }
 
 template <bool kMultiView>
-__global__ __launch_bounds__(256, kMultiView ? 1 : 2) void field_eval_kernel(FieldParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[kWavesPerWG * kTile * kStageRow];   // 64 KiB
+__global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? 1 : 2) void field_eval_kernel(FieldParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // 16 KiB per wave
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31;
     const int h = lane >> 5;
-    const long tile = (long)blockIdx.x * kWavesPerWG + wave;
-    if (tile >= p.n_tiles) return;                       // whole wave leaves; there are no barriers
     float* stage = lds + wave * (kTile * kStageRow);
+    if (MV_PRIO && !kMultiView && MV_WAVES == 8 && wave < 4) __builtin_amdgcn_s_setprio(1);
+
+  for (;;) {                                             // persistent: one 32-sample tile per trip
+#if MV_PERSIST
+    unsigned ticket = 0;
+    if (lane == 0) ticket = atomicAdd(p.tile_counter, 1u);
+    const long tile = (long)__builtin_amdgcn_readfirstlane(ticket);
+#else
+    const long tile = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+#endif
+    if (tile >= p.n_tiles) break;                        // whole wave leaves; there are no barriers
 
     long g = tile * kTile + j;
     const bool valid = g < p.total;
@@ -172,7 +233,11 @@ __global__ __launch_bounds__(256, kMultiView ? 1 : 2) void field_eval_kernel(Fie
 #pragma unroll
             for (int k = 0; k < kNFreq; ++k) {
                 const float arg = xin * (3.14159274101257324f * (float)(1 << k));   // fl32(pi)*2^k is exact
+#if MV_ABL_PE
+                pe[2 * k] = arg; pe[2 * k + 1] = arg + 1.0f;
+#else
                 sincos_f32(arg, &pe[2 * k], &pe[2 * k + 1]);
+#endif
             }
 #pragma unroll
             for (int gq = 0; gq < 5; ++gq) {
@@ -197,7 +262,7 @@ __global__ __launch_bounds__(256, kMultiView ? 1 : 2) void field_eval_kernel(Fie
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // earlier reads of `stage` are done
             const f32x4* fbase = reinterpret_cast<const f32x4*>(p.features) + hf * 32 + j;
 #pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
+            for (int it = 0; it < (MV_ABL_GATHER ? 0 : 16); ++it) {
                 const int src = 2 * it + h;                           // sample whose row this half-wave loads
                 const int tls = __shfl(tl, src);
                 const float axs = __shfl(tp.ax, src), ays = __shfl(tp.ay, src);
@@ -252,7 +317,7 @@ __global__ __launch_bounds__(256, kMultiView ? 1 : 2) void field_eval_kernel(Fie
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o = mfma(ws.cur[t][e], fmaxf(x[kb][4 * t + e], 0.0f), o);
+            for (int e = 0; e < 4; ++e) o = mfma(ws.cur[t][e], relu(x[kb][4 * t + e]), o);
         }
         if (kb < 3) {
 #pragma unroll
@@ -267,6 +332,10 @@ __global__ __launch_bounds__(256, kMultiView ? 1 : 2) void field_eval_kernel(Fie
         out[3] = softplus_f32(o[3]);
         *reinterpret_cast<f32x4*>(p.rgbs + 4 * g) = out;
     }
+#if !MV_PERSIST
+    break;
+#endif
+  }
 }
 
 // ---- weight packing -------------------------------------------------------------------------
@@ -320,12 +389,54 @@ hipError_t launch_pack_net(const float* net_keras, float* packed, hipStream_t st
     return hipGetLastError();
 }
 
-hipError_t launch_field_eval(const FieldParams& p, hipStream_t stream) {
-    const long wgs = (p.n_tiles + kWavesPerWG - 1) / kWavesPerWG;
+// Ticket counters for the persistent kernel: a small ring of device words so that launches in flight
+// on different streams never share one; the slot is zeroed on the launch stream right before use.
+constexpr int kCounterSlots = 64;
+__device__ unsigned int g_tile_counters[kCounterSlots];
+
+namespace {
+struct DeviceInfo {
+    int cus = 0;
+    unsigned int* counters = nullptr;
+    bool attr_set = false;
+};
+DeviceInfo g_dev[16];
+std::atomic<unsigned> g_launch_seq{0};
+std::mutex g_dev_mutex;
+}  // namespace
+
+hipError_t launch_field_eval(const FieldParams& p_in, hipStream_t stream) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    DeviceInfo& di = g_dev[dev];
+    {
+        std::lock_guard<std::mutex> lock(g_dev_mutex);
+        if (!di.attr_set) {
+            hipDeviceProp_t prop;
+            if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+            di.cus = prop.multiProcessorCount;
+            if ((e = hipGetSymbolAddress(reinterpret_cast<void**>(&di.counters), HIP_SYMBOL(g_tile_counters))) != hipSuccess) return e;
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_eval_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, MV_WAVES * kTile * kStageRow * 4)) != hipSuccess) return e;
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_eval_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTile * kStageRow * 4)) != hipSuccess) return e;
+            di.attr_set = true;
+        }
+    }
+    FieldParams p = p_in;
+    p.tile_counter = di.counters + (g_launch_seq.fetch_add(1) % kCounterSlots);
+    if ((e = hipMemsetAsync(p.tile_counter, 0, sizeof(unsigned int), stream)) != hipSuccess) return e;
+    const int waves = p.V > 1 ? 4 : MV_WAVES;
+    const long want = (p.n_tiles + waves - 1) / waves;
+    const long resident = (long)di.cus * (p.V > 1 ? 1 : 8 / MV_WAVES);   // workgroups that fit at once
+    const unsigned wgs = (unsigned)((MV_PERSIST && want > resident) ? resident : want);
+    const size_t lds_bytes = (size_t)waves * kTile * kStageRow * 4;
     if (p.V > 1)
-        hipLaunchKernelGGL(field_eval_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(field_eval_kernel<true>, dim3(wgs), dim3(256), lds_bytes, stream, p);
     else
-        hipLaunchKernelGGL(field_eval_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(field_eval_kernel<false>, dim3(wgs), dim3(64 * MV_WAVES), lds_bytes, stream, p);
     return hipGetLastError();
 }
 

@@ -21,6 +21,7 @@ struct FieldParams {
     int B, V, R, S, H, W;
     long total;            // B*R*S samples
     long n_tiles;          // ceil(total / 32)
+    unsigned int* tile_counter;   // set by launch_field_eval
 };
 
 hipError_t launch_pack_net(const float* net_keras, float* packed, hipStream_t stream);
