@@ -78,11 +78,13 @@ int mvnerf_stratified_depths(const float* u, int n_rays, int n_samples, double n
  * rgbs (B,R,S,4) = (r,g,b,sigma) per sample, 16-byte aligned.
  * tap_idx (optional, may be NULL): (B,V,R,S,4) int32 linear texel indices
  * (b*V+v)*H*W + y*W + x of the tl,tr,bl,br taps (the integer contract of a6).
- * pix (optional, may be NULL): (B,V,R,S,2) fp32 pixel locations (x,y). */
+ * pix (optional, may be NULL): (B,V,R,S,2) fp32 pixel locations (x,y).
+ * embedding (optional, may be NULL): (B,R,S,128) output of MVResNetMLPNeRFEmbedding (layers.py:379),
+ * 16-byte aligned. */
 int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, const float* images,
                       const float* features, const float* intrinsics, const float* extrinsics_inv,
                       const float* packed_net, int B, int V, int R, int S, int H, int W, float* rgbs,
-                      int32_t* tap_idx, float* pix, mvnerf_stream_t stream);
+                      int32_t* tap_idx, float* pix, float* embedding, mvnerf_stream_t stream);
 
 /* MVVNeRFRenderer.volumetric_render (model_v0.py:89-100) with sigma_to_alpha (nerf_utils.py:129-140).
  * z (n_rays,S); rgbs (n_rays,S,4); S in {64,128,192,256}.
@@ -97,6 +99,52 @@ int mvnerf_composite(const float* z, const float* rgbs, int n_rays, int S, float
 int mvnerf_resample(const float* z, const float* weights, const float* u_fine, int n_rays, int S,
                     int q7_mode, float* z_all, float* z_fine, int32_t* above, int32_t* below,
                     mvnerf_stream_t stream);
+
+/* ---- op-level (unfused) entry points: one per reference function, same scalar code as the fused
+ * kernels; used by the op-level parity tests and by callers that want a single operator. ---- */
+
+/* world = o + z*d (nerf_utils.py:59-60).  o,d (n_rays,3); z (n_rays,S) -> world (n_rays,S,3). */
+int mvnerf_points_on_rays(const float* rays_o, const float* rays_d, const float* z, int n_rays, int S, float* world,
+                          mvnerf_stream_t stream);
+
+/* compute_pixel_in_image_mv (nerf_utils.py:64-81).  world (B,N,3); intrinsics, extrinsics_inv (B,V,4,4)
+ * -> pixel_locations (B,V,N,2) [x,y], camera_points_homogeneous (B,V,N,4). */
+int mvnerf_project_points(const float* world, const float* intrinsics, const float* extrinsics_inv, int B, int V,
+                          int N, float* pixel_locations, float* camera_points, mvnerf_stream_t stream);
+
+/* world_to_camera_direction_vector_mv (nerf_utils.py:84-105; homogeneous w = 1).
+ * dirs (B,R,3); extrinsics_inv (B,V,4,4) -> (B,V,R,3). */
+int mvnerf_camera_directions(const float* dirs, const float* extrinsics_inv, int B, int V, int R, float* out,
+                             mvnerf_stream_t stream);
+
+/* position_encoding (nerf_utils.py:108-126).  x: n_elems scalars (any (...,D) flattened);
+ * out: n_elems * 2 * n_freq, layout per element [k][sin,cos] (=> (..., D*2*n_freq) as (d n f)). */
+int mvnerf_position_encoding(const float* x, long n_elems, int n_freq, float pos_encoding_freq, float* out,
+                             mvnerf_stream_t stream);
+
+/* get_projection_features_mv (nerf_utils.py:277-285): tensorflow_addons interpolate_bilinear
+ * (indexing='xy') of the grid [images | features].  images (BV,H,W,3) as given (the caller normalises),
+ * features (BV,H,W,256), pixel_locations (BV,Q,2) -> out (BV,Q,259); tap_idx (optional) (BV,Q,4) int32. */
+int mvnerf_bilinear_gather(const float* images, const float* features, const float* pixel_locations, int BV, int Q,
+                           int H, int W, float* out, int32_t* tap_idx, mvnerf_stream_t stream);
+
+/* sigma_to_alpha (nerf_utils.py:129-140), elementwise over n values. */
+int mvnerf_sigma_to_alpha(const float* sigma, const float* dists, long n, float* alpha, mvnerf_stream_t stream);
+
+/* sample_pdf (nerf_utils.py:143-176) with explicit uniforms.  bins (n_rays,63); weights (n_rays,62);
+ * u (n_rays,64) -> samples (n_rays,64); above / below (optional) (n_rays,64) int32. */
+int mvnerf_sample_pdf(const float* bins, const float* weights, const float* u, int n_rays, int n_bins, int n_samples,
+                      int q7_mode, float* samples, int32_t* above, int32_t* below, mvnerf_stream_t stream);
+
+/* RenderReadout (layers.py:392-397).  embedding (n,128); wr kernel[128,4], br bias[4] (Keras layout)
+ * -> rgbs (n,4) = (sigmoid rgb, softplus sigma). */
+int mvnerf_readout(const float* embedding, const float* wr, const float* br, long n, float* rgbs,
+                   mvnerf_stream_t stream);
+
+/* render_view epilogue (model_v0.py:275-281).  rgb (n,3), depth (n) -> rgb8 (n,3) = uint8(clip(rgb*255,0,255)),
+ * depth8 (n) = uint8(255*(depth-min)/(max-min)).  minmax_scratch: 2 floats of device scratch. */
+int mvnerf_finish_view(const float* rgb, const float* depth, long n, float* minmax_scratch, uint8_t* rgb8,
+                       uint8_t* depth8, mvnerf_stream_t stream);
 
 /* Bytes of scratch mvnerf_render_fwd needs for (B,R,S). */
 size_t mvnerf_render_workspace_bytes(int B, int R, int S);

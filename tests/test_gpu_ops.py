@@ -1,0 +1,145 @@
+"""Op-level parity: every reference function on the hot path through its own
+C-ABI entry point vs the oracle.  The geometry operators must be bit-identical (they decide the integer
+taps); transcendental ones carry a stated tolerance.  Written like the tests the reference never had."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mvnerf_oracle as O
+from thesis_clip_nerf_amd import nerf_utils as NU
+from thesis_clip_nerf_amd import ops
+from thesis_clip_nerf_amd.synthetic import make_scene
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+F32 = np.float32
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.fixture(scope='module')
+def scene():
+    return make_scene(seed=9, batch=2, n_views=3, height=20, width=28, n_rays=70, bias_scale=0.1)
+
+
+def test_sample_along_ray(scene):
+    sc = scene
+    w_ref, z_ref = O.sample_along_ray(sc['rays_o'], sc['rays_d'], 0.3, 1.3, 64, sc['u_coarse'])
+    w, z = NU.sample_along_ray(dev(sc['rays_o']), dev(sc['rays_d']), 0.3, 1.3, 2, 70, 64, u=dev(sc['u_coarse']))
+    np.testing.assert_array_equal(z.cpu().numpy(), z_ref)
+    np.testing.assert_array_equal(w.cpu().numpy(), w_ref)
+    with pytest.raises(ValueError):
+        NU.sample_along_ray(dev(sc['rays_o']), dev(sc['rays_d']), 0.3, 1.3, 1, 70, 64)
+    # default path draws its own uniforms on the device
+    _, z2 = NU.sample_along_ray(dev(sc['rays_o']), dev(sc['rays_d']), 0.3, 1.3, 2, 70, 64)
+    z2 = z2.cpu().numpy()
+    assert (np.diff(z2, axis=-1) >= 0).all() and z2.min() >= 0.3 and z2.max() <= 1.3 + 1e-6
+
+
+def test_compute_pixel_in_image_mv_and_directions(scene):
+    sc = scene
+    world, _ = O.sample_along_ray(sc['rays_o'], sc['rays_d'], 0.3, 1.3, 64, sc['u_coarse'])
+    pix_ref, cam_ref = O.compute_pixel_in_image_mv(world, sc['intrinsics'], sc['extrinsics_inv'])
+    pix, cam = NU.compute_pixel_in_image_mv(dev(world), dev(sc['intrinsics']), dev(sc['extrinsics_inv']))
+    np.testing.assert_array_equal(pix.cpu().numpy(), pix_ref)
+    np.testing.assert_array_equal(cam.cpu().numpy(), cam_ref)
+    d_ref = O.world_to_camera_direction_vector_mv(sc['rays_d'], sc['extrinsics_inv'])
+    d = NU.world_to_camera_direction_vector_mv(dev(sc['rays_d']), dev(sc['extrinsics_inv']), 3)
+    np.testing.assert_array_equal(d.cpu().numpy(), d_ref)
+
+
+def test_projection_behind_camera_and_clip():
+    # Q5: q_z <= 0 -> divide by 1e-8, clip to +-1e6 -> border texel
+    k4 = np.eye(4, dtype=F32)[None, None]
+    k4[0, 0, 0, 0] = k4[0, 0, 1, 1] = 50.0
+    einv = np.eye(4, dtype=F32)[None, None]
+    world = np.array([[[0.1, -0.2, -1.0], [0.0, 0.0, 0.0], [1e5, 3.0, 1e-9], [0.3, 0.3, 2.0]]], F32)
+    pix_ref, cam_ref = O.compute_pixel_in_image_mv(world[:, :, None, :], k4, einv)
+    pix, cam = ops.project_points(dev(world[:, :, None, :]), dev(k4), dev(einv))
+    np.testing.assert_array_equal(pix.cpu().numpy(), pix_ref)
+    assert np.abs(pix_ref).max() == 1e6
+
+
+def test_position_encoding(scene):
+    x = np.random.default_rng(0).uniform(-2, 2, (3, 5, 7, 3)).astype(F32)
+    ref = O.position_encoding(x)
+    got = NU.position_encoding(dev(x), 10, np.pi).cpu().numpy()
+    assert got.shape == ref.shape == (3, 5, 7, 60)
+    assert np.abs(got - ref).max() < 4e-7          # both within ~2 ulp of the exact sin/cos of the rounded product
+    got4 = NU.position_encoding(dev(x), 4, 1.0).cpu().numpy()
+    np.testing.assert_allclose(got4, O.position_encoding(x, 4, 1.0), atol=4e-7)
+
+
+def test_get_projection_features_mv(scene):
+    sc = scene
+    world, _ = O.sample_along_ray(sc['rays_o'], sc['rays_d'], 0.3, 1.3, 64, sc['u_coarse'])
+    pix, _ = O.compute_pixel_in_image_mv(world, sc['intrinsics'], sc['extrinsics_inv'])
+    norm = (sc['images'] * F32(2) - F32(1)).astype(F32)
+    ref = O.get_projection_features_mv(norm, sc['features'], pix)
+    got = NU.get_projection_features_mv(dev(norm), dev(sc['features']), dev(pix), 70, 64, 2).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)        # same fp32 op sequence as tfa's formula -> identical
+    b, v, h, w = 2, 3, 20, 28
+    out, taps = ops.bilinear_gather(dev(norm.reshape(b * v, h, w, 3)), dev(sc['features'].reshape(b * v, h, w, 256)),
+                                    dev(pix.reshape(b * v, -1, 2)), return_taps=True)
+    x0, y0, _, _ = O.bilinear_taps(pix.reshape(b * v, -1, 2), h, w)
+    ref_taps = O.tap_linear_indices(x0, y0, np.arange(b * v)[:, None], h, w)
+    np.testing.assert_array_equal(taps.cpu().numpy(), ref_taps)
+
+
+def test_sigma_to_alpha():
+    rng = np.random.default_rng(1)
+    sigma = rng.normal(2, 5, (4, 9, 64)).astype(F32)
+    dists = rng.random((4, 9, 64), dtype=F32) * F32(0.05)
+    got = NU.sigma_to_alpha(dev(sigma), dev(dists)).cpu().numpy()
+    assert np.abs(got - O.sigma_to_alpha(sigma, dists)).max() < 1.2e-7
+
+
+@pytest.mark.parametrize('q7', [O.Q7_ZERO, O.Q7_CLAMP])
+def test_sample_pdf(q7):
+    rng = np.random.default_rng(2)
+    bins = np.sort(rng.uniform(0.3, 1.3, (2, 50, 63)).astype(F32), -1)
+    w = (rng.random((2, 50, 62), dtype=F32) ** 3).astype(F32)
+    u = rng.random((2, 50, 64), dtype=F32)
+    u[..., 0] = np.nextafter(F32(1), F32(0))
+    ref, above_ref, below_ref = O.sample_pdf(bins, w, u, q7, return_indices=True)
+    got, above, below = ops.sample_pdf(dev(bins), dev(w), dev(u), q7, return_indices=True)
+    np.testing.assert_array_equal(above.cpu().numpy(), above_ref)
+    np.testing.assert_array_equal(below.cpu().numpy(), below_ref)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    np.testing.assert_array_equal(NU.sample_pdf(dev(bins), dev(w), 64, u=dev(u), q7_mode=q7).cpu().numpy(), ref)
+    with pytest.raises(ValueError):
+        ops.sample_pdf(dev(bins[..., :40]), dev(w[..., :39]), dev(u))
+
+
+def test_embedding_and_readout(scene):
+    sc = scene
+    d = {k: dev(sc[k]) for k in ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'coarse']}
+    _, z = O.sample_along_ray(sc['rays_o'], sc['rays_d'], 0.3, 1.3, 64, sc['u_coarse'])
+    net = O.unflatten_net(sc['coarse'])
+    # oracle embedding (layers.py:354-379) from the oracle's own projection / gather
+    world = O.points_on_rays(sc['rays_o'], sc['rays_d'], z)
+    pix, cam = O.compute_pixel_in_image_mv(world, sc['intrinsics'], sc['extrinsics_inv'])
+    feat = O.get_projection_features_mv((sc['images'] * F32(2) - F32(1)).astype(F32), sc['features'], pix)
+    cdir = O.world_to_camera_direction_vector_mv(sc['rays_d'], sc['extrinsics_inv'])
+    cdir = np.broadcast_to(cdir[:, :, :, None, :], cam.shape[:-1] + (3,))
+    emb_ref = O.mv_embedding(net, cam[..., :3].reshape(6, 70, 64, 3), cdir.reshape(6, 70, 64, 3), feat.reshape(6, 70, 64, 259), 3)
+    rgbs, emb = ops.field_eval(d['rays_o'], d['rays_d'], dev(z), d['images'], d['features'], d['intrinsics'],
+                               d['extrinsics_inv'], ops.pack_net(d['coarse']), return_embedding=True)
+    assert np.abs(emb.cpu().numpy() - emb_ref).max() < 2e-5
+    # stand-alone read-out on the oracle embedding
+    rgb_ref, sig_ref = O.render_readout(net, emb_ref)
+    out = ops.readout(dev(emb_ref), dev(net['Wr'].copy()), dev(net['br'].copy())).cpu().numpy()
+    assert np.abs(out[..., :3] - rgb_ref).max() < 1e-6 and np.abs(out[..., 3] - sig_ref).max() < 2e-6
+    assert np.abs(rgbs.cpu().numpy()[..., :3] - rgb_ref).max() < 1e-4
+
+
+def test_finish_view():
+    rng = np.random.default_rng(3)
+    rgb = rng.uniform(-0.1, 1.1, (30 * 40, 3)).astype(F32)
+    depth = rng.uniform(0.3, 1.3, 30 * 40).astype(F32)
+    ref_rgb, ref_d = O.finish_view(rgb, depth, (30, 40))
+    rgb8, d8 = ops.finish_view(dev(rgb), dev(depth))
+    np.testing.assert_array_equal(rgb8.cpu().numpy().reshape(30, 40, 3), ref_rgb)
+    np.testing.assert_array_equal(d8.cpu().numpy().reshape(30, 40, 1), ref_d)

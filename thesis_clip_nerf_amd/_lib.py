@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MVNERF_LIB', os.path.join(_HERE, 'lib', 'libmvnerf_hip.so'))   # override: A/B builds
@@ -27,10 +27,19 @@ SIGNATURES = {
     'mvnerf_get_rays': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
     'mvnerf_stratified_depths': (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p]),
-    'mvnerf_field_eval': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p] * 4),
+    'mvnerf_field_eval': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p] * 5),
     'mvnerf_composite': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mvnerf_resample': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
+    'mvnerf_points_on_rays': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'mvnerf_project_points': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'mvnerf_camera_directions': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'mvnerf_position_encoding': (c_int, [c_void_p, c_long, c_int, c_float, c_void_p, c_void_p]),
+    'mvnerf_bilinear_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'mvnerf_sigma_to_alpha': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
+    'mvnerf_sample_pdf': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mvnerf_readout': (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
+    'mvnerf_finish_view': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mvnerf_render_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'mvnerf_render_fwd': (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_double, c_double, c_int] + [c_void_p] * 6),
 }

@@ -86,7 +86,7 @@ int mvnerf_stratified_depths(const float* u, int n_rays, int n_samples, double n
 int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, const float* images,
                       const float* features, const float* intrinsics, const float* extrinsics_inv,
                       const float* packed_net, int B, int V, int R, int S, int H, int W, float* rgbs,
-                      int32_t* tap_idx, float* pix, mvnerf_stream_t stream) {
+                      int32_t* tap_idx, float* pix, float* embedding, mvnerf_stream_t stream) {
     if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !packed_net || !rgbs)
         return fail(MVNERF_E_ARG, "mvnerf_field_eval: null pointer");
     if (B <= 0 || V <= 0 || R <= 0 || S <= 0) return fail(MVNERF_E_ARG, "mvnerf_field_eval: B=%d V=%d R=%d S=%d", B, V, R, S);
@@ -94,11 +94,12 @@ int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, 
     const long total = (long)B * R * S;
     if (total >= (1L << 31) || (long)B * V * H * W >= (1L << 31))
         return fail(MVNERF_E_SHAPE, "mvnerf_field_eval: B*R*S=%ld or B*V*H*W too large for int32 indices", total);
-    if (!aligned16(features) || !aligned16(packed_net) || !aligned16(rgbs) || (tap_idx && !aligned16(tap_idx)))
-        return fail(MVNERF_E_ALIGN, "mvnerf_field_eval: features, packed_net, rgbs, tap_idx must be 16-byte aligned");
+    if (!aligned16(features) || !aligned16(packed_net) || !aligned16(rgbs) || (tap_idx && !aligned16(tap_idx)) ||
+        (embedding && !aligned16(embedding)))
+        return fail(MVNERF_E_ALIGN, "mvnerf_field_eval: features, packed_net, rgbs, tap_idx, embedding must be 16-byte aligned");
     mvnerf::FieldParams p;
     p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.images = images; p.features = features;
-    p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs; p.tap_idx = tap_idx; p.pix = pix;
+    p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs; p.tap_idx = tap_idx; p.pix = pix; p.embedding = embedding;
     p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W;
     p.total = total;
     p.n_tiles = (total + 31) / 32;
@@ -126,6 +127,82 @@ int mvnerf_resample(const float* z, const float* weights, const float* u_fine, i
                       "mvnerf_resample");
 }
 
+int mvnerf_points_on_rays(const float* rays_o, const float* rays_d, const float* z, int n_rays, int S, float* world,
+                          mvnerf_stream_t stream) {
+    if (!rays_o || !rays_d || !z || !world) return fail(MVNERF_E_ARG, "mvnerf_points_on_rays: null pointer");
+    if (n_rays <= 0 || S <= 0) return fail(MVNERF_E_ARG, "mvnerf_points_on_rays: n_rays=%d S=%d", n_rays, S);
+    return hip_status(mvnerf::launch_points_on_rays(rays_o, rays_d, z, (long)n_rays * S, S, world, static_cast<hipStream_t>(stream)),
+                      "mvnerf_points_on_rays");
+}
+
+int mvnerf_project_points(const float* world, const float* intrinsics, const float* extrinsics_inv, int B, int V, int N,
+                          float* pixel_locations, float* camera_points, mvnerf_stream_t stream) {
+    if (!world || !intrinsics || !extrinsics_inv || !pixel_locations || !camera_points)
+        return fail(MVNERF_E_ARG, "mvnerf_project_points: null pointer");
+    if (B <= 0 || V <= 0 || N <= 0) return fail(MVNERF_E_ARG, "mvnerf_project_points: B=%d V=%d N=%d", B, V, N);
+    return hip_status(mvnerf::launch_project_points(world, intrinsics, extrinsics_inv, B, V, N, pixel_locations, camera_points,
+                                                    static_cast<hipStream_t>(stream)),
+                      "mvnerf_project_points");
+}
+
+int mvnerf_camera_directions(const float* dirs, const float* extrinsics_inv, int B, int V, int R, float* out,
+                             mvnerf_stream_t stream) {
+    if (!dirs || !extrinsics_inv || !out) return fail(MVNERF_E_ARG, "mvnerf_camera_directions: null pointer");
+    if (B <= 0 || V <= 0 || R <= 0) return fail(MVNERF_E_ARG, "mvnerf_camera_directions: B=%d V=%d R=%d", B, V, R);
+    return hip_status(mvnerf::launch_camera_directions(dirs, extrinsics_inv, B, V, R, out, static_cast<hipStream_t>(stream)),
+                      "mvnerf_camera_directions");
+}
+
+int mvnerf_position_encoding(const float* x, long n_elems, int n_freq, float pos_encoding_freq, float* out,
+                             mvnerf_stream_t stream) {
+    if (!x || !out) return fail(MVNERF_E_ARG, "mvnerf_position_encoding: null pointer");
+    if (n_elems <= 0 || n_freq <= 0 || n_freq > 32) return fail(MVNERF_E_ARG, "mvnerf_position_encoding: n_elems=%ld n_freq=%d", n_elems, n_freq);
+    return hip_status(mvnerf::launch_position_encoding(x, n_elems, n_freq, pos_encoding_freq, out, static_cast<hipStream_t>(stream)),
+                      "mvnerf_position_encoding");
+}
+
+int mvnerf_bilinear_gather(const float* images, const float* features, const float* pixel_locations, int BV, int Q, int H,
+                           int W, float* out, int32_t* tap_idx, mvnerf_stream_t stream) {
+    if (!images || !features || !pixel_locations || !out) return fail(MVNERF_E_ARG, "mvnerf_bilinear_gather: null pointer");
+    if (BV <= 0 || Q <= 0) return fail(MVNERF_E_ARG, "mvnerf_bilinear_gather: BV=%d Q=%d", BV, Q);
+    if (H < 2 || W < 2) return fail(MVNERF_E_SHAPE, "mvnerf_bilinear_gather: grid %dx%d, need H,W >= 2", H, W);
+    if ((long)BV * H * W >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_bilinear_gather: BV*H*W too large for int32 indices");
+    return hip_status(mvnerf::launch_bilinear_gather(images, features, pixel_locations, BV, Q, H, W, out, tap_idx,
+                                                     static_cast<hipStream_t>(stream)),
+                      "mvnerf_bilinear_gather");
+}
+
+int mvnerf_sigma_to_alpha(const float* sigma, const float* dists, long n, float* alpha, mvnerf_stream_t stream) {
+    if (!sigma || !dists || !alpha) return fail(MVNERF_E_ARG, "mvnerf_sigma_to_alpha: null pointer");
+    if (n <= 0) return fail(MVNERF_E_ARG, "mvnerf_sigma_to_alpha: n=%ld", n);
+    return hip_status(mvnerf::launch_sigma_to_alpha(sigma, dists, n, alpha, static_cast<hipStream_t>(stream)), "mvnerf_sigma_to_alpha");
+}
+
+int mvnerf_sample_pdf(const float* bins, const float* weights, const float* u, int n_rays, int n_bins, int n_samples,
+                      int q7_mode, float* samples, int32_t* above, int32_t* below, mvnerf_stream_t stream) {
+    if (!bins || !weights || !u || !samples) return fail(MVNERF_E_ARG, "mvnerf_sample_pdf: null pointer");
+    if (n_rays <= 0) return fail(MVNERF_E_ARG, "mvnerf_sample_pdf: n_rays=%d", n_rays);
+    if (n_bins != 63 || n_samples != 64)
+        return fail(MVNERF_E_SHAPE, "mvnerf_sample_pdf: n_bins=%d n_samples=%d, only the reference's 63 bins / 64 samples is built", n_bins, n_samples);
+    if (q7_mode != MVNERF_Q7_ZERO && q7_mode != MVNERF_Q7_CLAMP) return fail(MVNERF_E_ARG, "mvnerf_sample_pdf: q7_mode=%d", q7_mode);
+    return hip_status(mvnerf::launch_sample_pdf(bins, weights, u, n_rays, q7_mode, samples, above, below, static_cast<hipStream_t>(stream)),
+                      "mvnerf_sample_pdf");
+}
+
+int mvnerf_readout(const float* embedding, const float* wr, const float* br, long n, float* rgbs, mvnerf_stream_t stream) {
+    if (!embedding || !wr || !br || !rgbs) return fail(MVNERF_E_ARG, "mvnerf_readout: null pointer");
+    if (n <= 0) return fail(MVNERF_E_ARG, "mvnerf_readout: n=%ld", n);
+    return hip_status(mvnerf::launch_readout(embedding, wr, br, n, rgbs, static_cast<hipStream_t>(stream)), "mvnerf_readout");
+}
+
+int mvnerf_finish_view(const float* rgb, const float* depth, long n, float* minmax_scratch, uint8_t* rgb8, uint8_t* depth8,
+                       mvnerf_stream_t stream) {
+    if (!rgb || !depth || !minmax_scratch || !rgb8 || !depth8) return fail(MVNERF_E_ARG, "mvnerf_finish_view: null pointer");
+    if (n <= 0) return fail(MVNERF_E_ARG, "mvnerf_finish_view: n=%ld", n);
+    return hip_status(mvnerf::launch_finish_view(rgb, depth, n, minmax_scratch, rgb8, depth8, static_cast<hipStream_t>(stream)),
+                      "mvnerf_finish_view");
+}
+
 size_t mvnerf_render_workspace_bytes(int B, int R, int S) {
     if (B <= 0 || R <= 0 || S <= 0) return 0;
     return carve(nullptr, (long)B * R, S).bytes;
@@ -147,13 +224,13 @@ int mvnerf_render_fwd(const float* rays_o, const float* rays_d, const float* ima
     int rc;
     if ((rc = mvnerf_stratified_depths(u_coarse, (int)n_rays, S, near_, far_, w.z, stream))) return rc;
     if ((rc = mvnerf_field_eval(rays_o, rays_d, w.z, images, features, intrinsics, extrinsics_inv, packed_coarse, B, V,
-                                R, S, H, W, w.rgbs_c, nullptr, nullptr, stream)))
+                                R, S, H, W, w.rgbs_c, nullptr, nullptr, nullptr, stream)))
         return rc;
     if ((rc = mvnerf_composite(w.z, w.rgbs_c, (int)n_rays, S, rgb, depth, w.weights, stream))) return rc;
     if ((rc = mvnerf_resample(w.z, w.weights, u_fine, (int)n_rays, S, q7_mode, w.z_all, nullptr, nullptr, nullptr, stream)))
         return rc;
     if ((rc = mvnerf_field_eval(rays_o, rays_d, w.z_all, images, features, intrinsics, extrinsics_inv, packed_fine, B,
-                                V, R, 2 * S, H, W, w.rgbs_f, nullptr, nullptr, stream)))
+                                V, R, 2 * S, H, W, w.rgbs_f, nullptr, nullptr, nullptr, stream)))
         return rc;
     return mvnerf_composite(w.z_all, w.rgbs_f, (int)n_rays, 2 * S, fine_rgb, fine_depth, nullptr, stream);
 }

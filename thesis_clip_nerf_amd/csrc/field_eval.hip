@@ -22,19 +22,17 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kTile = 32;            // samples per wavefront (MFMA N dimension)
-// Persistent workgroups, one per CU.  Single-view: 8 waves = 2 per SIMD, where the first four run at
-// raised priority: each SIMD's matrix pipe then always serves one wave at full rate and its partner
-// fills the gaps left by that wave's gather / sin-cos / wait phases, instead of the two identical
-// instruction streams running in lock-step and stalling together.  Tiles are handed out through an
-// atomic counter (zeroed by the launcher before every launch), so the uneven progress balances out.
+// Launch shape: measured best ("Field kernel: what was measured") is the plain one: one
+// 32-sample tile per wave, 4 waves per workgroup, 2 workgroups per CU (2 waves per SIMD).  The
+// persistent / ticket-queue / raised-priority forms below are kept as build switches for A/B runs.
 constexpr int kStageRow = 128;       // floats per staged sample row (half of the 256 channels)
 
 // Tuning switches (A/B-tested on the GPU, see DESIGN.md "Field kernel: what was measured")
 #ifndef MV_PERSIST
-#define MV_PERSIST 1       // 1: one workgroup per CU pulling tiles from an atomic ticket; 0: one tile per wave
+#define MV_PERSIST 0       // 1: one workgroup per CU pulling tiles from an atomic ticket; 0: one tile per wave
 #endif
 #ifndef MV_PRIO
-#define MV_PRIO 1          // raise the priority of waves 0..3 of an 8-wave workgroup
+#define MV_PRIO 0          // raise the priority of waves 0..3 of an 8-wave workgroup
 #endif
 #ifndef MV_ABL_PE
 #define MV_ABL_PE 0        // timing-only ablations (wrong results): skip sin/cos
@@ -51,8 +49,11 @@ constexpr int kStageRow = 128;       // floats per staged sample row (half of th
 #ifndef MV_PIN_LOADS
 #define MV_PIN_LOADS 1
 #endif
+#ifndef MV_ASM_RELU
+#define MV_ASM_RELU 0
+#endif
 #ifndef MV_WAVES
-#define MV_WAVES 8         // waves per workgroup of the single-view kernel (4 or 8)
+#define MV_WAVES 4         // waves per workgroup of the single-view kernel (4 or 8)
 #endif
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
@@ -62,21 +63,48 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 // relu as one v_med3_f32 (fmaxf lowers to a canonicalising v_max pair in front of every MFMA)
 __device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
 
+// relu of the 4 B operands of a step as four single v_max_f32 (fmaxf lowers to a canonicalising
+// v_max pair + s_nop in front of every MFMA).  The trailing s_nop 1 covers the VALU-write ->
+// MFMA-read wait states for the compiler-scheduled MFMAs that consume the outputs.
+__device__ __forceinline__ void relu4(const float (&in)[4], float (&b)[4]) {
+#if MV_ASM_RELU
+    asm("v_max_f32_e32 %0, 0, %4\n\tv_max_f32_e32 %1, 0, %5\n\tv_max_f32_e32 %2, 0, %6\n\tv_max_f32_e32 %3, 0, %7\n\ts_nop 1"
+        : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+        : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]));
+#else
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[e] = fmaxf(in[e], 0.0f);
+#endif
+}
+
 // The weight stream: `cur` holds the 4 chunks (4 KiB per wave) of the step being consumed, `next`
 // points at this lane's 16 bytes of the following step.  Every step first issues the loads of the
 // following step, then runs its 16 MFMAs (1024 cycles of matrix pipe), so an L2 round trip is
 // always covered, also across layer boundaries (the chunks of all layers are contiguous).
 struct WStream {
-    const f32x4* next;
+    __amdgpu_buffer_rsrc_t rsrc;   // buffer descriptor of the packed net (SGPRs)
+    int voff;                      // lane * 16
+    int pos;                       // wave-uniform byte offset of the NEXT step (SGPR)
     f32x4 cur[4];
 };
 
-__device__ __forceinline__ void ws_begin(WStream& ws, const f32x4* first) {
-    ws.cur[0] = first[0];
-    ws.cur[1] = first[64];
-    ws.cur[2] = first[128];
-    ws.cur[3] = first[192];
-    ws.next = first + 256;
+// buffer_load_dwordx4 v, voff, rsrc, pos offen offset:imm -- the uniform stream position rides in the
+// scalar offset and the chunk index in the immediate, so a step costs no VALU address arithmetic.
+template <int kImm>
+__device__ __forceinline__ f32x4 ws_load(const WStream& ws, int pos) {
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff + kImm, pos, 0);
+    return __builtin_bit_cast(f32x4, r);
+}
+
+__device__ __forceinline__ void ws_begin(WStream& ws, const float* net, int lane) {
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(net), 0, kPackTotal * 4, 0x00020000);
+    ws.voff = lane * 16;
+    ws.cur[0] = ws_load<0>(ws, 0);
+    ws.cur[1] = ws_load<1024>(ws, 0);
+    ws.cur[2] = ws_load<2048>(ws, 0);
+    ws.cur[3] = ws_load<3072>(ws, 0);
+    ws.pos = 4096;
 }
 
 // One step = 4 k-steps x 4 output blocks: acc[nb] += A(cur[nb])[e] x b[e]
@@ -84,7 +112,8 @@ __device__ __forceinline__ void mfma_step(WStream& ws, const float (&b)[4], f32x
 #if MV_ABL_WLOAD
     const f32x4 n0 = ws.cur[1], n1 = ws.cur[2], n2 = ws.cur[3], n3 = ws.cur[0];
 #else
-    const f32x4 n0 = ws.next[0], n1 = ws.next[64], n2 = ws.next[128], n3 = ws.next[192];
+    const f32x4 n0 = ws_load<0>(ws, ws.pos), n1 = ws_load<1024>(ws, ws.pos), n2 = ws_load<2048>(ws, ws.pos),
+                n3 = ws_load<3072>(ws, ws.pos);
 #endif
 #if MV_PIN_LOADS
     __builtin_amdgcn_sched_barrier(0);      // keep the prefetch a full step ahead of its use
@@ -100,7 +129,7 @@ __device__ __forceinline__ void mfma_step(WStream& ws, const float (&b)[4], f32x
     ws.cur[1] = n1;
     ws.cur[2] = n2;
     ws.cur[3] = n3;
-    ws.next += 256;
+    ws.pos += 4096;
 }
 
 template <bool kAdd>
@@ -135,9 +164,9 @@ __device__ __forceinline__ void dense128(WStream& ws, const f32x16 (&in)[4], f32
     for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+            const float raw[4] = {in[kb][4 * t], in[kb][4 * t + 1], in[kb][4 * t + 2], in[kb][4 * t + 3]};
             float b[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) b[e] = relu(in[kb][4 * t + e]);
+            relu4(raw, b);
             mfma_step(ws, b, acc);
         }
     }
@@ -190,14 +219,13 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? 1 : 
     const float wx = ox + zz * dx, wy = oy + zz * dy, wz = oz + zz * dz;     // mul, then add (no FMA)
 
     const float* __restrict__ net = p.net;
-    const f32x4* wbase = reinterpret_cast<const f32x4*>(net) + lane;
 
     f32x16 x[4], hid[4];
     f32x16 xsum[kMultiView ? 4 : 1];
     WStream ws;
 
     for (int v = 0; v < p.V; ++v) {
-        ws_begin(ws, wbase);                             // layer-0 group 0 (re-read per view)
+        ws_begin(ws, net, lane);                         // layer-0 group 0 (re-read per view)
         const int bv = b * p.V + v;
         const float* E = p.einv + 16 * bv;
         const float* K = p.k4 + 16 * bv;
@@ -301,6 +329,17 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? 1 : 
 #pragma unroll 1
     for (int bi = 3; bi < 6; ++bi) resnet_block(ws, net + kPackBHidden + 256 * bi, h, x, hid);
 
+    if (p.embedding && valid) {                          // optional: trunk output (layers.py:379), 128 floats per sample
+        float* e = p.embedding + 128 * g + 4 * h;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v4 = {x[nb][4 * q], x[nb][4 * q + 1], x[nb][4 * q + 2], x[nb][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(e + 32 * nb + 8 * q) = v4;
+            }
+    }
+
     // ---- read-out: Dense 128 -> 4 on relu(x), sigmoid / softplus (layers.py:392-397) ----
     // the stream now holds read-out chunks (kb, t = 0..3); rows 0..3 of the 32-row tile are real
     f32x16 o;
@@ -310,9 +349,11 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? 1 : 
     for (int kb = 0; kb < 4; ++kb) {
         f32x4 n[4];
         if (kb < 3) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) n[t] = ws.next[64 * t];
-            ws.next += 256;
+            n[0] = ws_load<0>(ws, ws.pos);
+            n[1] = ws_load<1024>(ws, ws.pos);
+            n[2] = ws_load<2048>(ws, ws.pos);
+            n[3] = ws_load<3072>(ws, ws.pos);
+            ws.pos += 4096;
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {

@@ -18,6 +18,7 @@ struct FieldParams {
     float* rgbs;
     int32_t* tap_idx;      // optional
     float* pix;            // optional
+    float* embedding;      // optional (B,R,S,128): trunk output before the read-out
     int B, V, R, S, H, W;
     long total;            // B*R*S samples
     long n_tiles;          // ceil(total / 32)
@@ -36,5 +37,21 @@ hipError_t launch_composite(const float* z, const float* rgbs, int n_rays, int S
                             float* weights, hipStream_t stream);
 hipError_t launch_resample(const float* z, const float* weights, const float* u_fine, int n_rays, int q7_mode,
                            float* z_all, float* z_fine, int32_t* above, int32_t* below, hipStream_t stream);
+
+hipError_t launch_sample_pdf(const float* bins, const float* weights, const float* u, int n_rays, int q7_mode,
+                             float* samples, int32_t* above, int32_t* below, hipStream_t stream);
+
+// unfused_ops.hip
+hipError_t launch_points_on_rays(const float* o, const float* d, const float* z, long n, int S, float* out, hipStream_t st);
+hipError_t launch_project_points(const float* world, const float* k4, const float* einv, int B, int V, long N,
+                                 float* pix, float* cam, hipStream_t st);
+hipError_t launch_camera_directions(const float* d, const float* einv, int B, int V, int R, float* out, hipStream_t st);
+hipError_t launch_position_encoding(const float* x, long n_elems, int n_freq, float freq0, float* out, hipStream_t st);
+hipError_t launch_bilinear_gather(const float* images, const float* features, const float* pix, int BV, long Q, int H,
+                                  int W, float* out, int32_t* taps, hipStream_t st);
+hipError_t launch_sigma_to_alpha(const float* sigma, const float* dists, long n, float* alpha, hipStream_t st);
+hipError_t launch_readout(const float* emb, const float* wr, const float* br, long n, float* rgbs, hipStream_t st);
+hipError_t launch_finish_view(const float* rgb, const float* depth, long n, float* minmax, uint8_t* rgb8, uint8_t* depth8,
+                              hipStream_t st);
 
 }  // namespace mvnerf

@@ -169,6 +169,44 @@ hipError_t launch_composite(const float* z, const float* rgbs, int n_rays, int S
 // The sums that decide the integer outputs (w_sum, cdf) are strictly sequential in fp32, as in the
 // oracle: every lane runs the same 62-step loop over wave-private LDS (broadcast reads), so all
 // lanes hold bit-identical values.  `above` is the reference's tf.scan: a count of cdf_j <= u.
+// Core of sample_pdf for one ray on one wavefront.  On entry bins[0..62] and pdf[0..61] (= weights +
+// 1e-5) are in wave-private LDS and fenced; lane l draws the sample for uniform u.
+__device__ __forceinline__ float sample_pdf_core(const float* bins, float* pdf, float* cdf, int lane, float u,
+                                                 int q7_mode, int& above, int& below) {
+    constexpr int NB = 63, NW = 62;
+    float wsum = 0.0f;
+    for (int k = 0; k < NW; ++k) wsum = wsum + pdf[k];               // sequential
+    if (fabsf(wsum) == 0.0f) wsum = 1.0f;                            // :146
+    lds_fence();
+    if (lane < NW) pdf[lane] = pdf[lane] / wsum;
+    lds_fence();
+    float run = 0.0f, mycdf = 0.0f;
+    for (int k = 0; k < NW; ++k) {                                   // cdf_j = sum_{k<j} pdf_k, sequential
+        run = run + pdf[k];
+        if (lane == k + 1) mycdf = run;
+    }
+    if (lane < NB) cdf[lane] = mycdf;                                // cdf_0 = 0 (:149)
+    lds_fence();
+
+    above = 0;
+    for (int jj = 0; jj < NB; ++jj) above += (u >= cdf[jj]) ? 1 : 0;  // tf.scan(greater_equal) (:156-160)
+    below = above - 1;
+    below = below < 0 ? 0 : (below > NB - 1 ? NB - 1 : below);       // :162
+    // Q7: `above` may be NB (one past the end).  TF-GPU gather_nd yields 0 there; optional clamp.
+    const bool oob = above >= NB;
+    const int ia = oob ? NB - 1 : above;
+    float cdf_a = cdf[ia], bins_a = bins[ia];
+    if (oob && q7_mode == 0) {
+        cdf_a = 0.0f;
+        bins_a = 0.0f;
+    }
+    const float cdf_b = cdf[below], bins_b = bins[below];
+    float den = cdf_a - cdf_b;
+    if (den < 1e-5f) den = 1.0f;
+    const float t = (u - cdf_b) / den;
+    return bins_b + t * (bins_a - bins_b);
+}
+
 __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ z, const float* __restrict__ weights,
                                                        const float* __restrict__ u_fine, int n_rays, int q7_mode,
                                                        float* __restrict__ z_all, float* __restrict__ z_fine,
@@ -194,38 +232,8 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     if (lane >= 1 && lane <= NW) pdf[lane - 1] = wi + 1e-5f;         // probs = weights[1:-1] (+1e-5, :144)
     vals[lane] = zi;
     lds_fence();
-    float wsum = 0.0f;
-    for (int k = 0; k < NW; ++k) wsum = wsum + pdf[k];               // sequential
-    if (fabsf(wsum) == 0.0f) wsum = 1.0f;                            // :146
-    lds_fence();
-    if (lane < NW) pdf[lane] = pdf[lane] / wsum;
-    lds_fence();
-    float run = 0.0f, mycdf = 0.0f;
-    for (int k = 0; k < NW; ++k) {                                   // cdf_j = sum_{k<j} pdf_k, sequential
-        run = run + pdf[k];
-        if (lane == k + 1) mycdf = run;
-    }
-    if (lane < NB) cdf[lane] = mycdf;                                // cdf_0 = 0 (:149)
-    lds_fence();
-
-    const float u = u_fine[base + lane];
-    int above = 0;
-    for (int jj = 0; jj < NB; ++jj) above += (u >= cdf[jj]) ? 1 : 0;  // tf.scan(greater_equal) (:156-160)
-    int below = above - 1;
-    below = below < 0 ? 0 : (below > NB - 1 ? NB - 1 : below);       // :162
-    // Q7: `above` may be NB (one past the end).  TF-GPU gather_nd yields 0 there; optional clamp.
-    const bool oob = above >= NB;
-    const int ia = oob ? NB - 1 : above;
-    float cdf_a = cdf[ia], bins_a = bins[ia];
-    if (oob && q7_mode == 0) {
-        cdf_a = 0.0f;
-        bins_a = 0.0f;
-    }
-    const float cdf_b = cdf[below], bins_b = bins[below];
-    float den = cdf_a - cdf_b;
-    if (den < 1e-5f) den = 1.0f;
-    const float t = (u - cdf_b) / den;
-    const float zf = bins_b + t * (bins_a - bins_b);
+    int above, below;
+    const float zf = sample_pdf_core(bins, pdf, cdf, lane, u_fine[base + lane], q7_mode, above, below);
     if (z_fine) z_fine[base + lane] = zf;
     if (above_out) above_out[base + lane] = above;
     if (below_out) below_out[base + lane] = below;
@@ -244,6 +252,37 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     lds_fence();
     z_all[(long)ray * 128 + lane] = sorted[lane];
     z_all[(long)ray * 128 + 64 + lane] = sorted[64 + lane];
+}
+
+// sample_pdf (nerf_utils.py:143-176) on explicit bins (n,63), weights (n,62), u (n,64)
+__global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict__ bins_in,
+                                                         const float* __restrict__ weights, const float* __restrict__ u,
+                                                         int n_rays, int q7_mode, float* __restrict__ samples,
+                                                         int32_t* __restrict__ above_out,
+                                                         int32_t* __restrict__ below_out) {
+    __shared__ float lds[kRaysPerWG][3 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int ray = blockIdx.x * kRaysPerWG + wv;
+    if (ray >= n_rays) return;
+    float* bins = lds[wv];
+    float* pdf = bins + 64;
+    float* cdf = pdf + 64;
+    if (lane < 63) bins[lane] = bins_in[(long)ray * 63 + lane];
+    if (lane < 62) pdf[lane] = weights[(long)ray * 62 + lane] + 1e-5f;
+    lds_fence();
+    int above, below;
+    const float zf = sample_pdf_core(bins, pdf, cdf, lane, u[(long)ray * 64 + lane], q7_mode, above, below);
+    samples[(long)ray * 64 + lane] = zf;
+    if (above_out) above_out[(long)ray * 64 + lane] = above;
+    if (below_out) below_out[(long)ray * 64 + lane] = below;
+}
+
+hipError_t launch_sample_pdf(const float* bins, const float* weights, const float* u, int n_rays, int q7_mode,
+                             float* samples, int32_t* above, int32_t* below, hipStream_t stream) {
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3((n_rays + kRaysPerWG - 1) / kRaysPerWG), dim3(256), 0, stream, bins,
+                       weights, u, n_rays, q7_mode, samples, above, below);
+    return hipGetLastError();
 }
 
 hipError_t launch_resample(const float* z, const float* weights, const float* u_fine, int n_rays, int q7_mode,

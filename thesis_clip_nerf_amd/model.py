@@ -1,0 +1,217 @@
+"""Host-side mirror of the reference renderer (src/lib/mvnerf/model_v0.py) on top of the HIP library.
+
+Same names and argument meaning as the reference so that a `train_nerf.py`-style script (or a
+test) reads the same:
+
+* :class:`MVVNeRFRenderer` - ``_call`` / ``infer`` / ``call`` / ``volumetric_render`` / ``store`` /
+  ``load`` (model_v0.py:16-240).  The two MLPs are held as flat Keras-order fp32 buffers
+  (``kernel[in,out]``, ``bias[out]``); the image encoders (``VisualFeatures``, CLIP,
+  ``CombineCLIPVisual*``) are NOT part of the hot path: their output ``combined_features``
+  (B,V,H,W,256) is an input here, or comes from a user-supplied ``feature_encoder`` callable.
+* :func:`render_view` (model_v0.py:243-281) - full-image driver, device resident (no per-chunk
+  host round trip, source images uploaded once).
+* :func:`render` - the ``render(rays, model) -> rgb, depth`` surface named in BASELINE.json.
+
+Differences that are deliberate: image size and ray count are not baked into
+signatures; the uniforms that the reference draws inside the graph with ``tf.random.uniform``
+(nerf_utils.py:57,151) can be passed explicitly (``u_coarse``, ``u_fine``) and otherwise come from
+``torch.rand`` on the device (optionally with a ``generator``).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import NET_PARAMS, Q7_ZERO
+from .synthetic import glorot_net
+
+_SUBMODELS = ('coarse_embedding', 'coarse_readout', 'fine_embedding', 'fine_readout')
+_EMB_PARAMS = NET_PARAMS - (128 * 4 + 4)      # trunk part of the flat buffer; the rest is the read-out
+
+
+class MVVNeRFRenderer:
+    """model_v0.py:16-44.  Holds the coarse and fine MLP weights and runs `_call` on the GPU."""
+
+    def __init__(self, n_rays_train, n_rays_infer, n_views=2, n_samples=64, n_features=256,
+                 embed_direction_vector=True, batch_size=1, near=0.7, far=1.5, original_image_size=(480, 640),
+                 device='cuda', seed=0, feature_encoder=None, q7_mode=Q7_ZERO):
+        if n_features != 256:
+            raise ValueError('n_features must be 256 (the HIP kernels are built for the reference feature width)')
+        if not embed_direction_vector:
+            raise ValueError('embed_direction_vector=False is not built (every reference config sets True)')
+        if n_samples != 64:
+            raise ValueError('n_samples must be 64 (reference config nerf_model/default.yaml:3)')
+        self.n_views = n_views
+        self.n_samples = n_samples
+        self.n_rays_train = n_rays_train
+        self.n_rays_infer = n_rays_infer
+        self.batch_size = batch_size
+        self.infer_batch_size = 1
+        self.near = near
+        self.far = far
+        self.original_image_size = tuple(original_image_size)
+        self.device = torch.device(device)
+        self.feature_encoder = feature_encoder
+        self.q7_mode = q7_mode
+        rng = np.random.default_rng(seed)
+        self.coarse_net = torch.from_numpy(glorot_net(rng)).to(self.device)      # Keras glorot_uniform, zero bias
+        self.fine_net = torch.from_numpy(glorot_net(rng)).to(self.device)
+        self._packed = None
+        self._workspace = None
+
+    # ---- weights -------------------------------------------------------------------------
+    def set_weights(self, coarse_net=None, fine_net=None):
+        """Replace the flat Keras-order buffers (247 300 fp32 each) and drop the packed images."""
+        for name, val in (('coarse_net', coarse_net), ('fine_net', fine_net)):
+            if val is not None:
+                val = torch.as_tensor(val, dtype=torch.float32).reshape(-1).to(self.device).contiguous()
+                if val.numel() != NET_PARAMS:
+                    raise ValueError(f'{name}: {val.numel()} parameters, expected {NET_PARAMS}')
+                setattr(self, name, val)
+        self._packed = None
+
+    def weights_changed(self):
+        """Call after updating coarse_net / fine_net in place (e.g. an optimizer step)."""
+        self._packed = None
+
+    def packed(self):
+        if self._packed is None:
+            self._packed = (ops.pack_net(self.coarse_net), ops.pack_net(self.fine_net))
+        return self._packed
+
+    # ---- forward -------------------------------------------------------------------------
+    def encode(self, image):
+        """model_v0.py:47-49 - image encoder hook; out of the hot-path scope."""
+        if self.feature_encoder is None:
+            raise NotImplementedError('no feature_encoder configured: pass combined_features explicitly '
+                                      '(the conv/ViT/CLIP encoders are outside the render hot path)')
+        return self.feature_encoder(image)
+
+    def _uniforms(self, b, r, u_coarse, u_fine, generator):
+        shape = (b, r, self.n_samples)
+        if u_coarse is None:
+            u_coarse = torch.rand(shape, dtype=torch.float32, device=self.device, generator=generator)
+        if u_fine is None:
+            u_fine = torch.rand(shape, dtype=torch.float32, device=self.device, generator=generator)
+        return u_coarse, u_fine
+
+    def _call(self, inputs, n_rays, batch_size, combined_features, u_coarse=None, u_fine=None, generator=None):
+        """model_v0.py:113-184.  inputs = (ray_origins (B,R,3), ray_directions (B,R,3),
+        images (B,V,H,W,3) in [0,1], intrinsics (B,V,4,4), extrinsics_inv (B,V,4,4)).
+        Returns (rgb, depth, fine_rgb, fine_depth)."""
+        rays_o, rays_d, images, k4, einv = [self._dev(t) for t in inputs]
+        features = self._dev(combined_features)
+        if rays_o.dim() != 3 or rays_o.shape[0] != batch_size or rays_o.shape[1] != n_rays:
+            raise ValueError(f'ray_origins: shape {tuple(rays_o.shape)}, expected ({batch_size}, {n_rays}, 3)')
+        u_coarse, u_fine = self._uniforms(batch_size, n_rays, u_coarse, u_fine, generator)
+        pc, pf = self.packed()
+        need = ops.render_workspace_bytes(batch_size, n_rays, self.n_samples)
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ops.render_fwd(rays_o, rays_d, images, features, k4, einv, pc, pf, self._dev(u_coarse), self._dev(u_fine),
+                              self.near, self.far, self.q7_mode, workspace=self._workspace)
+
+    def infer(self, inputs, batched_features, **kw):
+        """model_v0.py:61-63 (any ray count, not only n_rays_infer=512)."""
+        return self._call(inputs, inputs[0].shape[1], inputs[0].shape[0], batched_features, **kw)
+
+    def call(self, inputs, training=False, combined_features=None, **kw):
+        """model_v0.py:75-87: encoder prologue (pluggable) + `_call`."""
+        if combined_features is None:
+            b, v = inputs[2].shape[:2]
+            feats = self.encode(self._dev(inputs[2]).reshape(b * v, *inputs[2].shape[2:]))
+            combined_features = feats.reshape(b, v, *feats.shape[1:])
+        return self._call(inputs, inputs[0].shape[1], inputs[0].shape[0], combined_features, **kw)
+
+    __call__ = call
+
+    @staticmethod
+    def volumetric_render(zs, density, chromacity):
+        """model_v0.py:89-100 -> (rgb, depth, weights)."""
+        rgbs = torch.cat([chromacity, density[..., None]], dim=-1).contiguous()
+        return ops.composite(zs.contiguous(), rgbs, return_weights=True)
+
+    # ---- checkpoint (model_v0.py:199-240; per-sub-model files, load() -> False if any is missing) ----
+    def _split(self, flat):
+        return flat[:_EMB_PARAMS], flat[_EMB_PARAMS:]
+
+    def store(self, path):
+        parts = dict(zip(_SUBMODELS, (*self._split(self.coarse_net), *self._split(self.fine_net))))
+        for name, t in parts.items():
+            torch.save(t.detach().cpu(), f'{path}_{name}.pt')
+
+    def load(self, path, old=False):
+        files = [f'{path}_{name}.pt' for name in _SUBMODELS]
+        if not all(os.path.exists(f) for f in files):
+            return False
+        ce, cr, fe, fr = [torch.load(f, weights_only=True) for f in files]
+        self.set_weights(torch.cat([ce, cr]), torch.cat([fe, fr]))
+        return True
+
+    def _dev(self, t):
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
+        return t.to(self.device, dtype=torch.float32).contiguous()
+
+
+def camera_parameters(camera_config):
+    """data_generator/util.py:4-10: (extrinsics_inv, intrinsics padded to 4x4), float64 NumPy."""
+    k = np.reshape(camera_config['intrinsics'], (3, 3))
+    k4 = np.concatenate((k, np.zeros((3, 1))), axis=1)
+    k4 = np.concatenate((k4, np.array([[0, 0, 0, 1]])), axis=0)
+    return np.linalg.inv(camera_config['pose']), k4
+
+
+def render(rays, model, *, features, images, K4, Einv, near=None, far=None, n_samples=64, u_coarse=None, u_fine=None,
+           generator=None, return_coarse=False):
+    """render(rays, model) -> (rgb, depth): the fine pair by default, the reference 4-tuple
+    (rgb, depth, fine_rgb, fine_depth) (model_v0.py:184) with return_coarse=True.
+    rays = (origins (B,R,3), directions (B,R,3))."""
+    if n_samples != model.n_samples:
+        raise ValueError(f'n_samples={n_samples} but the model was built with {model.n_samples}')
+    saved = model.near, model.far
+    if near is not None:
+        model.near = near
+    if far is not None:
+        model.far = far
+    try:
+        out = model._call((rays[0], rays[1], images, K4, Einv), rays[0].shape[1], rays[0].shape[0], features,
+                          u_coarse=u_coarse, u_fine=u_fine, generator=generator)
+    finally:
+        model.near, model.far = saved
+    return out if return_coarse else (out[2], out[3])
+
+
+def render_view(model, src_colors, src_camera_configs, tgt_camera_config, combined_features=None, generator=None,
+                chunk=None):
+    """model_v0.py:243-281.  src_colors: list of (H,W,>=3) uint8 images; camera configs: dicts with
+    'pose' (4x4) and 'intrinsics' (9,).  Returns (rgb (H,W,3) uint8, depth (H,W,1) uint8) as NumPy.
+    Everything between the upload of the source views and the download of the two uint8 images stays on
+    the device; `chunk` rays per `_call` (default: the whole image in one call)."""
+    dev = model.device
+    tgt_k = np.reshape(tgt_camera_config['intrinsics'], (3, 3)).astype(np.float32)
+    h, w = src_colors[0].shape[:2]
+    pose = np.asarray(tgt_camera_config['pose'], dtype=np.float64)
+    m = pose[:3, :3] @ np.linalg.inv(tgt_k[:3, :3])                      # nerf_utils.py:30, host LAPACK as the reference
+    rays_o, rays_d = ops.get_rays_device(m, pose[:3, 3], dev, width=w, height=h)
+    src = np.array([[img[..., :3] / 255.0 for img in src_colors]])         # (1,V,H,W,3), model_v0.py:253
+    images = torch.from_numpy(src.astype(np.float32)).to(dev)
+    cams = [camera_parameters(c) for c in src_camera_configs]              # data_generator/mvnerf.py:28-43
+    einv = torch.from_numpy(np.array([[c[0] for c in cams]], dtype=np.float32)).to(dev)
+    k4 = torch.from_numpy(np.array([[c[1] for c in cams]], dtype=np.float32)).to(dev)
+    if combined_features is None:
+        feats = model.encode(images.reshape(-1, h, w, 3))
+        combined_features = feats.reshape(1, len(src_colors), *feats.shape[1:])
+    n = h * w
+    chunk = n if chunk is None else int(chunk)
+    rgbs = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    depths = torch.empty((n,), dtype=torch.float32, device=dev)
+    for i in range(0, n, chunk):
+        sl = slice(i, min(n, i + chunk))
+        out = model.infer((rays_o[None, sl], rays_d[None, sl], images, k4, einv), combined_features, generator=generator)
+        rgbs[sl], depths[sl] = out[2][0], out[3][0]
+    rgb8, depth8 = ops.finish_view(rgbs, depths)
+    return rgb8.reshape(h, w, 3).cpu().numpy(), depth8.reshape(h, w, 1).cpu().numpy()

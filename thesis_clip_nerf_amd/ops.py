@@ -86,8 +86,8 @@ def stratified_depths(u, near, far):
 
 
 def field_eval(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, return_taps=False,
-               return_pix=False):
-    """mvnerf_field_eval: -> rgbs (B,R,S,4) [+ tap_idx (B,V,R,S,4) int32] [+ pix (B,V,R,S,2)]."""
+               return_pix=False, return_embedding=False):
+    """mvnerf_field_eval: -> rgbs (B,R,S,4) [+ tap_idx (B,V,R,S,4) int32] [+ pix (B,V,R,S,2)] [+ embedding (B,R,S,128)]."""
     _chk(rays_o, 'rays_o', shape=(None, None, 3))
     b, r, _ = rays_o.shape
     _chk(rays_d, 'rays_d', shape=(b, r, 3))
@@ -103,16 +103,19 @@ def field_eval(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, 
     rgbs = torch.empty((b, r, s, 4), dtype=torch.float32, device=dev)
     taps = torch.empty((b, v, r, s, 4), dtype=torch.int32, device=dev) if return_taps else None
     pix = torch.empty((b, v, r, s, 2), dtype=torch.float32, device=dev) if return_pix else None
+    emb = torch.empty((b, r, s, 128), dtype=torch.float32, device=dev) if return_embedding else None
     with torch.cuda.device(dev):
         rc = _lib.lib().mvnerf_field_eval(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(intrinsics),
                                           _p(extrinsics_inv), _p(packed_net), b, v, r, s, h, w, _p(rgbs), _p(taps),
-                                          _p(pix), _stream(rays_o))
+                                          _p(pix), _p(emb), _stream(rays_o))
     _lib.check(rc, 'field_eval')
     out = (rgbs,)
     if return_taps:
         out += (taps,)
     if return_pix:
         out += (pix,)
+    if return_embedding:
+        out += (emb,)
     return out if len(out) > 1 else rgbs
 
 
@@ -189,3 +192,131 @@ def render_fwd(rays_o, rays_d, images, features, intrinsics, extrinsics_inv, pac
                                           _p(depth), _p(fine_rgb), _p(fine_depth), _p(workspace), _stream(rays_o))
     _lib.check(rc, 'render_fwd')
     return rgb, depth, fine_rgb, fine_depth
+
+
+# ---- op-level (unfused) operators: one per reference function ---------------------------------------
+def points_on_rays(rays_o, rays_d, z):
+    """o + z*d: rays (...,3), z (...,S) -> (...,S,3)."""
+    _chk(rays_o, 'rays_o')
+    _chk(rays_d, 'rays_d', shape=tuple(rays_o.shape))
+    _chk(z, 'z', shape=tuple(rays_o.shape[:-1]) + (None,))
+    s = z.shape[-1]
+    out = torch.empty(tuple(z.shape) + (3,), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        rc = _lib.lib().mvnerf_points_on_rays(_p(rays_o), _p(rays_d), _p(z), z.numel() // s, s, _p(out), _stream(z))
+    _lib.check(rc, 'points_on_rays')
+    return out
+
+
+def project_points(world, intrinsics, extrinsics_inv):
+    """compute_pixel_in_image_mv: world (B,...,3) -> pix (B,V,...,2), cam (B,V,...,4)."""
+    _chk(world, 'world')
+    b = world.shape[0]
+    _chk(intrinsics, 'intrinsics', shape=(b, None, 4, 4))
+    v = intrinsics.shape[1]
+    _chk(extrinsics_inv, 'extrinsics_inv', shape=(b, v, 4, 4))
+    mid = tuple(world.shape[1:-1])
+    n = world.numel() // (3 * b)
+    pix = torch.empty((b, v) + mid + (2,), dtype=torch.float32, device=world.device)
+    cam = torch.empty((b, v) + mid + (4,), dtype=torch.float32, device=world.device)
+    with torch.cuda.device(world.device):
+        rc = _lib.lib().mvnerf_project_points(_p(world), _p(intrinsics), _p(extrinsics_inv), b, v, n, _p(pix), _p(cam),
+                                              _stream(world))
+    _lib.check(rc, 'project_points')
+    return pix, cam
+
+
+def camera_directions(dirs, extrinsics_inv):
+    """world_to_camera_direction_vector_mv: dirs (B,R,3) -> (B,V,R,3)."""
+    _chk(dirs, 'dirs', shape=(None, None, 3))
+    b, r, _ = dirs.shape
+    _chk(extrinsics_inv, 'extrinsics_inv', shape=(b, None, 4, 4))
+    v = extrinsics_inv.shape[1]
+    out = torch.empty((b, v, r, 3), dtype=torch.float32, device=dirs.device)
+    with torch.cuda.device(dirs.device):
+        rc = _lib.lib().mvnerf_camera_directions(_p(dirs), _p(extrinsics_inv), b, v, r, _p(out), _stream(dirs))
+    _lib.check(rc, 'camera_directions')
+    return out
+
+
+def position_encoding(position, n_freq=10, pos_encoding_freq=np.pi):
+    """position (...,D) -> (..., D*2*n_freq), layout (d, k, {sin,cos})."""
+    _chk(position, 'position')
+    out = torch.empty(tuple(position.shape[:-1]) + (position.shape[-1] * 2 * n_freq,), dtype=torch.float32,
+                      device=position.device)
+    with torch.cuda.device(position.device):
+        rc = _lib.lib().mvnerf_position_encoding(_p(position), position.numel(), int(n_freq),
+                                                 float(np.float32(pos_encoding_freq)), _p(out), _stream(position))
+    _lib.check(rc, 'position_encoding')
+    return out
+
+
+def bilinear_gather(images, features, pixel_locations, return_taps=False):
+    """images (N,H,W,3), features (N,H,W,256), pixel_locations (N,Q,2) -> (N,Q,259) [+ taps (N,Q,4)]."""
+    _chk(images, 'images', shape=(None, None, None, 3))
+    n, h, w, _ = images.shape
+    _chk(features, 'features', shape=(n, h, w, 256))
+    _chk(pixel_locations, 'pixel_locations', shape=(n, None, 2))
+    q = pixel_locations.shape[1]
+    out = torch.empty((n, q, 259), dtype=torch.float32, device=images.device)
+    taps = torch.empty((n, q, 4), dtype=torch.int32, device=images.device) if return_taps else None
+    with torch.cuda.device(images.device):
+        rc = _lib.lib().mvnerf_bilinear_gather(_p(images), _p(features), _p(pixel_locations), n, q, h, w, _p(out),
+                                               _p(taps), _stream(images))
+    _lib.check(rc, 'bilinear_gather')
+    return (out, taps) if return_taps else out
+
+
+def sigma_to_alpha(sigma, dists):
+    _chk(sigma, 'sigma')
+    _chk(dists, 'dists', shape=tuple(sigma.shape))
+    out = torch.empty_like(sigma)
+    with torch.cuda.device(sigma.device):
+        rc = _lib.lib().mvnerf_sigma_to_alpha(_p(sigma), _p(dists), sigma.numel(), _p(out), _stream(sigma))
+    _lib.check(rc, 'sigma_to_alpha')
+    return out
+
+
+def sample_pdf(bins, weights, u, q7_mode=Q7_ZERO, return_indices=False):
+    """bins (...,63), weights (...,62), u (...,64) -> samples (...,64) [+ above, below int32]."""
+    _chk(bins, 'bins')
+    lead = tuple(bins.shape[:-1])
+    _chk(weights, 'weights', shape=lead + (None,))
+    _chk(u, 'u', shape=lead + (None,))
+    n = bins.numel() // bins.shape[-1]
+    samples = torch.empty_like(u)
+    above = torch.empty(u.shape, dtype=torch.int32, device=u.device) if return_indices else None
+    below = torch.empty(u.shape, dtype=torch.int32, device=u.device) if return_indices else None
+    if weights.shape[-1] != bins.shape[-1] - 1:
+        raise ValueError(f'weights: last dim {weights.shape[-1]}, expected {bins.shape[-1] - 1}')
+    with torch.cuda.device(u.device):
+        rc = _lib.lib().mvnerf_sample_pdf(_p(bins), _p(weights), _p(u), n, bins.shape[-1], u.shape[-1], int(q7_mode),
+                                          _p(samples), _p(above), _p(below), _stream(u))
+    _lib.check(rc, 'sample_pdf')
+    return (samples, above, below) if return_indices else samples
+
+
+def readout(embedding, wr, br):
+    """RenderReadout: embedding (...,128), wr (128,4), br (4,) -> rgbs (...,4)."""
+    _chk(embedding, 'embedding', shape=tuple(embedding.shape[:-1]) + (128,))
+    _chk(wr, 'wr', shape=(128, 4))
+    _chk(br, 'br', shape=(4,))
+    out = torch.empty(tuple(embedding.shape[:-1]) + (4,), dtype=torch.float32, device=embedding.device)
+    with torch.cuda.device(embedding.device):
+        rc = _lib.lib().mvnerf_readout(_p(embedding), _p(wr), _p(br), embedding.numel() // 128, _p(out), _stream(embedding))
+    _lib.check(rc, 'readout')
+    return out
+
+
+def finish_view(rgb, depth):
+    """render_view epilogue: rgb (n,3), depth (n) -> (rgb8 (n,3) uint8, depth8 (n) uint8)."""
+    _chk(depth, 'depth')
+    n = depth.numel()
+    _chk(rgb, 'rgb', shape=tuple(depth.shape) + (3,))
+    rgb8 = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
+    depth8 = torch.empty(depth.shape, dtype=torch.uint8, device=rgb.device)
+    scratch = torch.empty(2, dtype=torch.float32, device=rgb.device)
+    with torch.cuda.device(rgb.device):
+        rc = _lib.lib().mvnerf_finish_view(_p(rgb), _p(depth), n, _p(scratch), _p(rgb8), _p(depth8), _stream(rgb))
+    _lib.check(rc, 'finish_view')
+    return rgb8, depth8
