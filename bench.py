@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from thesis_clip_nerf_amd import ops  # noqa: E402
+from thesis_clip_nerf_amd.distributed import max_over_ranks  # noqa: E402
 from thesis_clip_nerf_amd.synthetic import make_scene  # noqa: E402
 
 FLOP_PER_SAMPLE_V1 = 491264          # BASELINE.md 3 (2 x 245 632 MAC), one source view
@@ -104,10 +105,7 @@ def main():
         out = step(ev[i])
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(elapsed, dev)            # the slowest rank's clock (no-op at world 1)
 
     rays_per_step = b * r * world
     ms_per_step = 1e3 * elapsed / args.steps
