@@ -467,8 +467,11 @@ hipError_t launch_field_eval(const FieldParams& p_in, hipStream_t stream) {
         }
     }
     FieldParams p = p_in;
+    p.tile_counter = nullptr;
+#if MV_PERSIST
     p.tile_counter = di.counters + (g_launch_seq.fetch_add(1) % kCounterSlots);
     if ((e = hipMemsetAsync(p.tile_counter, 0, sizeof(unsigned int), stream)) != hipSuccess) return e;
+#endif
     const int waves = p.V > 1 ? 4 : MV_WAVES;
     const long want = (p.n_tiles + waves - 1) / waves;
     const long resident = (long)di.cus * (p.V > 1 ? 1 : 8 / MV_WAVES);   // workgroups that fit at once
