@@ -80,11 +80,16 @@ int mvnerf_stratified_depths(const float* u, int n_rays, int n_samples, double n
  * (b*V+v)*H*W + y*W + x of the tl,tr,bl,br taps (the integer contract of a6).
  * pix (optional, may be NULL): (B,V,R,S,2) fp32 pixel locations (x,y).
  * embedding (optional, may be NULL): (B,R,S,128) output of MVResNetMLPNeRFEmbedding (layers.py:379),
- * 16-byte aligned. */
+ * 16-byte aligned.
+ * acts_per_view (optional): (4, B*V, R, S, 128) and acts_fused (optional): (4, B, R, S, 128): the eight
+ * activations the trunk returns with complete_output=True (layers.py:364-377): [x0, f1, f2, f3] per view and
+ * [mean, u1, u2, u3] after the view mean; this is what LanguageNeRF consumes (lmvnerf/model_v4.py:261-262).
+ * Arbitrary query points (not on rays): pass the points as rays_o, their directions as rays_d, z = 0, S = 1. */
 int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, const float* images,
                       const float* features, const float* intrinsics, const float* extrinsics_inv,
                       const float* packed_net, int B, int V, int R, int S, int H, int W, float* rgbs,
-                      int32_t* tap_idx, float* pix, float* embedding, mvnerf_stream_t stream);
+                      int32_t* tap_idx, float* pix, float* embedding, float* acts_per_view, float* acts_fused,
+                      mvnerf_stream_t stream);
 
 /* MVVNeRFRenderer.volumetric_render (model_v0.py:89-100) with sigma_to_alpha (nerf_utils.py:129-140).
  * z (n_rays,S); rgbs (n_rays,S,4); S in {64,128,192,256}.

@@ -38,9 +38,9 @@ def test_argument_validation_without_gpu():
     assert lib.mvnerf_composite(one, one, 4, 100, one, one, None, None) == -2          # S=100 unsupported
     assert lib.mvnerf_resample(one, one, one, 4, 32, 0, one, None, None, None, None) == -2
     assert lib.mvnerf_field_eval(one, one, one, one, ctypes.c_void_p(20), one, one, one, 1, 1, 4, 64, 8, 8, one, None,
-                                 None, None, None) == -3                                 # misaligned features
+                                 None, None, None, None, None) == -3                                 # misaligned features
     assert lib.mvnerf_field_eval(one, one, one, one, one, one, one, one, 1, 1, 4, 64, 1, 8, one, None, None, None,
-                                 None) == -2                                             # H < 2
+                                 None, None, None) == -2                                             # H < 2
     assert lib.mvnerf_sample_pdf(one, one, one, 4, 33, 64, 0, one, None, None, None) == -2  # only 63 bins is built
 
 

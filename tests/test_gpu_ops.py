@@ -143,3 +143,34 @@ def test_finish_view():
     rgb8, d8 = ops.finish_view(dev(rgb), dev(depth))
     np.testing.assert_array_equal(rgb8.cpu().numpy().reshape(30, 40, 3), ref_rgb)
     np.testing.assert_array_equal(d8.cpu().numpy().reshape(30, 40, 1), ref_d)
+
+
+def test_complete_output_and_query_field(scene):
+    """Trunk as a field on arbitrary points with complete_output (layers.py:364-377), the only other live
+    consumer of the hot path (lmvnerf/model_v4.py:217-262): 8 activations vs the oracle."""
+    sc = scene
+    rng = np.random.default_rng(11)
+    n = 75                                                     # not a multiple of the 32-sample tile
+    pts = rng.uniform(-0.25, 0.25, (2, n, 3)).astype(F32)
+    dirs = rng.standard_normal((2, n, 3)).astype(F32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    net = O.unflatten_net(sc['fine'])
+    world = pts[:, :, None, :]                                  # (B,N,1,3): one "sample" per query point
+    pix, cam = O.compute_pixel_in_image_mv(world, sc['intrinsics'], sc['extrinsics_inv'])
+    feat = O.get_projection_features_mv((sc['images'] * F32(2) - F32(1)).astype(F32), sc['features'], pix)
+    cdir = O.world_to_camera_direction_vector_mv(dirs, sc['extrinsics_inv'])[:, :, :, None, :]
+    ref = O.mv_embedding(net, cam[..., :3].reshape(6, n, 1, 3), np.ascontiguousarray(cdir).reshape(6, n, 1, 3),
+                         feat.reshape(6, n, 1, 259), 3, complete_output=True)
+    d = {k: dev(sc[k]) for k in ['images', 'features', 'intrinsics', 'extrinsics_inv', 'fine']}
+    packed = ops.pack_net(d['fine'])
+    rgbs, acts = ops.query_field(dev(pts), dev(dirs), d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'],
+                                 packed, complete_output=True)
+    assert len(acts) == 8
+    for i, (a, r) in enumerate(zip(acts, ref)):
+        a = a.cpu().numpy()
+        assert a.shape == r[:, :, 0].shape == ((6 if i < 4 else 2), n, 128)
+        assert np.abs(a - r[:, :, 0]).max() < 2e-5, i
+    rgbs2, emb = ops.query_field(dev(pts), dev(dirs), d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'], packed)
+    assert torch.equal(rgbs, rgbs2) and torch.equal(emb, acts[7])
+    rgb_ref, sig_ref = O.render_readout(net, ref[7][:, :, 0])
+    assert np.abs(rgbs.cpu().numpy()[..., :3] - rgb_ref).max() < 1e-5

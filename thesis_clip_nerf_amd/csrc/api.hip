@@ -86,7 +86,8 @@ int mvnerf_stratified_depths(const float* u, int n_rays, int n_samples, double n
 int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, const float* images,
                       const float* features, const float* intrinsics, const float* extrinsics_inv,
                       const float* packed_net, int B, int V, int R, int S, int H, int W, float* rgbs,
-                      int32_t* tap_idx, float* pix, float* embedding, mvnerf_stream_t stream) {
+                      int32_t* tap_idx, float* pix, float* embedding, float* acts_per_view, float* acts_fused,
+                      mvnerf_stream_t stream) {
     if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !packed_net || !rgbs)
         return fail(MVNERF_E_ARG, "mvnerf_field_eval: null pointer");
     if (B <= 0 || V <= 0 || R <= 0 || S <= 0) return fail(MVNERF_E_ARG, "mvnerf_field_eval: B=%d V=%d R=%d S=%d", B, V, R, S);
@@ -95,11 +96,12 @@ int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, 
     if (total >= (1L << 31) || (long)B * V * H * W >= (1L << 31))
         return fail(MVNERF_E_SHAPE, "mvnerf_field_eval: B*R*S=%ld or B*V*H*W too large for int32 indices", total);
     if (!aligned16(features) || !aligned16(packed_net) || !aligned16(rgbs) || (tap_idx && !aligned16(tap_idx)) ||
-        (embedding && !aligned16(embedding)))
+        (embedding && !aligned16(embedding)) || (acts_per_view && !aligned16(acts_per_view)) ||
+        (acts_fused && !aligned16(acts_fused)))
         return fail(MVNERF_E_ALIGN, "mvnerf_field_eval: features, packed_net, rgbs, tap_idx, embedding must be 16-byte aligned");
     mvnerf::FieldParams p;
     p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.images = images; p.features = features;
-    p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs; p.tap_idx = tap_idx; p.pix = pix; p.embedding = embedding;
+    p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs; p.tap_idx = tap_idx; p.pix = pix; p.embedding = embedding; p.acts_view = acts_per_view; p.acts_fused = acts_fused;
     p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W;
     p.total = total;
     p.n_tiles = (total + 31) / 32;
@@ -224,13 +226,13 @@ int mvnerf_render_fwd(const float* rays_o, const float* rays_d, const float* ima
     int rc;
     if ((rc = mvnerf_stratified_depths(u_coarse, (int)n_rays, S, near_, far_, w.z, stream))) return rc;
     if ((rc = mvnerf_field_eval(rays_o, rays_d, w.z, images, features, intrinsics, extrinsics_inv, packed_coarse, B, V,
-                                R, S, H, W, w.rgbs_c, nullptr, nullptr, nullptr, stream)))
+                                R, S, H, W, w.rgbs_c, nullptr, nullptr, nullptr, nullptr, nullptr, stream)))
         return rc;
     if ((rc = mvnerf_composite(w.z, w.rgbs_c, (int)n_rays, S, rgb, depth, w.weights, stream))) return rc;
     if ((rc = mvnerf_resample(w.z, w.weights, u_fine, (int)n_rays, S, q7_mode, w.z_all, nullptr, nullptr, nullptr, stream)))
         return rc;
     if ((rc = mvnerf_field_eval(rays_o, rays_d, w.z_all, images, features, intrinsics, extrinsics_inv, packed_fine, B,
-                                V, R, 2 * S, H, W, w.rgbs_f, nullptr, nullptr, nullptr, stream)))
+                                V, R, 2 * S, H, W, w.rgbs_f, nullptr, nullptr, nullptr, nullptr, nullptr, stream)))
         return rc;
     return mvnerf_composite(w.z_all, w.rgbs_f, (int)n_rays, 2 * S, fine_rgb, fine_depth, nullptr, stream);
 }

@@ -187,6 +187,18 @@ __device__ __forceinline__ void resnet_block(WStream& ws, const float* __restric
     dense128(ws, hid, x);
 }
 
+// lane (j,h) holds features 32*nb + 8*q + 4*h + {0..3} of sample j in registers 4q..4q+3 of block nb
+__device__ __forceinline__ void store_acc(float* __restrict__ row128, int h, const f32x16 (&x)[4]) {
+    float* e = row128 + 4 * h;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v4 = {x[nb][4 * q], x[nb][4 * q + 1], x[nb][4 * q + 2], x[nb][4 * q + 3]};
+            *reinterpret_cast<f32x4*>(e + 32 * nb + 8 * q) = v4;
+        }
+}
+
 __device__ __forceinline__ int stage_offset(int row, int chunk) {      // floats; XOR swizzle on 16-B chunks
     return row * kStageRow + ((chunk ^ (row & 15)) << 2);
 }
@@ -349,9 +361,15 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? 1 : 
             }
         }
 
-        // ---- per-view feature blocks (layers.py:365-366) ----
+        // ---- per-view feature blocks (layers.py:365-366); optional complete_output taps (:376-377) ----
+        const long vrow = ((long)bv * p.R + (ray - b * p.R)) * p.S + sidx;       // row in a (B*V,R,S,128) tensor
+        const long vslot = (long)p.B * p.V * p.R * p.S * 128;
+        if (p.acts_view && valid) store_acc(p.acts_view + 128 * vrow, h, x);
 #pragma unroll 1
-        for (int bi = 0; bi < 3; ++bi) resnet_block(ws, net + kPackBHidden + 256 * bi, h, x, hid);
+        for (int bi = 0; bi < 3; ++bi) {
+            resnet_block(ws, net + kPackBHidden + 256 * bi, h, x, hid);
+            if (p.acts_view && valid) store_acc(p.acts_view + (bi + 1) * vslot + 128 * vrow, h, x);
+        }
 
         if (kMultiView) {                                             // reduce_mean over views (layers.py:368-370)
 #pragma unroll
@@ -365,19 +383,14 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? 1 : 
     }
 
     // ---- fusion blocks (layers.py:373-374); the stream continues into hidden layer 6 ----
+    if (p.acts_fused && valid) store_acc(p.acts_fused + 128 * g, h, x);           // the view mean
 #pragma unroll 1
-    for (int bi = 3; bi < 6; ++bi) resnet_block(ws, net + kPackBHidden + 256 * bi, h, x, hid);
-
-    if (p.embedding && valid) {                          // optional: trunk output (layers.py:379), 128 floats per sample
-        float* e = p.embedding + 128 * g + 4 * h;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v4 = {x[nb][4 * q], x[nb][4 * q + 1], x[nb][4 * q + 2], x[nb][4 * q + 3]};
-                *reinterpret_cast<f32x4*>(e + 32 * nb + 8 * q) = v4;
-            }
+    for (int bi = 3; bi < 6; ++bi) {
+        resnet_block(ws, net + kPackBHidden + 256 * bi, h, x, hid);
+        if (p.acts_fused && valid) store_acc(p.acts_fused + (bi - 2) * p.total * 128 + 128 * g, h, x);
     }
+
+    if (p.embedding && valid) store_acc(p.embedding + 128 * g, h, x);   // optional: trunk output (layers.py:379)
 
     // ---- read-out: Dense 128 -> 4 on relu(x), sigmoid / softplus (layers.py:392-397) ----
     // the stream now holds read-out chunks (kb, t = 0..3); rows 0..3 of the 32-row tile are real

@@ -19,6 +19,8 @@ struct FieldParams {
     int32_t* tap_idx;      // optional
     float* pix;            // optional
     float* embedding;      // optional (B,R,S,128): trunk output before the read-out
+    float* acts_view;      // optional (4,B*V,R,S,128): layer 0 and the 3 per-view blocks (complete_output)
+    float* acts_fused;     // optional (4,B,R,S,128): view mean and the 3 fusion blocks (complete_output)
     int B, V, R, S, H, W;
     long total;            // B*R*S samples
     long n_tiles;          // ceil(total / 32)

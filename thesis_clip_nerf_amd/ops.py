@@ -86,7 +86,7 @@ def stratified_depths(u, near, far):
 
 
 def field_eval(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, return_taps=False,
-               return_pix=False, return_embedding=False):
+               return_pix=False, return_embedding=False, complete_output=False):
     """mvnerf_field_eval: -> rgbs (B,R,S,4) [+ tap_idx (B,V,R,S,4) int32] [+ pix (B,V,R,S,2)] [+ embedding (B,R,S,128)]."""
     _chk(rays_o, 'rays_o', shape=(None, None, 3))
     b, r, _ = rays_o.shape
@@ -104,10 +104,12 @@ def field_eval(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, 
     taps = torch.empty((b, v, r, s, 4), dtype=torch.int32, device=dev) if return_taps else None
     pix = torch.empty((b, v, r, s, 2), dtype=torch.float32, device=dev) if return_pix else None
     emb = torch.empty((b, r, s, 128), dtype=torch.float32, device=dev) if return_embedding else None
+    acts_v = torch.empty((4, b * v, r, s, 128), dtype=torch.float32, device=dev) if complete_output else None
+    acts_f = torch.empty((4, b, r, s, 128), dtype=torch.float32, device=dev) if complete_output else None
     with torch.cuda.device(dev):
         rc = _lib.lib().mvnerf_field_eval(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(intrinsics),
                                           _p(extrinsics_inv), _p(packed_net), b, v, r, s, h, w, _p(rgbs), _p(taps),
-                                          _p(pix), _p(emb), _stream(rays_o))
+                                          _p(pix), _p(emb), _p(acts_v), _p(acts_f), _stream(rays_o))
     _lib.check(rc, 'field_eval')
     out = (rgbs,)
     if return_taps:
@@ -116,7 +118,23 @@ def field_eval(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, 
         out += (pix,)
     if return_embedding:
         out += (emb,)
+    if complete_output:               # the reference's `outputs` list (layers.py:364-377): 4 per-view + 4 fused
+        out += (list(acts_v.unbind(0)) + list(acts_f.unbind(0)),)
     return out if len(out) > 1 else rgbs
+
+
+def query_field(points, dirs, images, features, intrinsics, extrinsics_inv, packed_net, complete_output=False):
+    """Trunk as a field on arbitrary points (lmvnerf/model_v4.py:217-262 use of fine_embedding):
+    points, dirs (B,N,3) -> rgbs (B,N,4) and either the embedding (B,N,128) or, with complete_output, the
+    list of 8 activations [x0,f1,f2,f3 (B*V,N,128) | mean,u1,u2,u3 (B,N,128)]."""
+    _chk(points, 'points', shape=(None, None, 3))
+    z = torch.zeros(tuple(points.shape[:2]) + (1,), dtype=torch.float32, device=points.device)   # p = o + 0*d = o
+    res = field_eval(points, dirs, z, images, features, intrinsics, extrinsics_inv, packed_net,
+                     return_embedding=not complete_output, complete_output=complete_output)
+    rgbs, extra = res[0], res[1]
+    if complete_output:
+        return rgbs[:, :, 0], [a[:, :, 0] for a in extra]
+    return rgbs[:, :, 0], extra[:, :, 0]
 
 
 def composite(z, rgbs, return_weights=True):
