@@ -74,7 +74,7 @@ def main():
          ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'u_coarse', 'u_fine', 'coarse', 'fine']}
     pc, pf = ops.pack_net(t['coarse']), ops.pack_net(t['fine'])
     b, r, s = t['u_coarse'].shape
-    ws = torch.empty(ops.render_workspace_bytes(b, r, s), dtype=torch.uint8, device=dev)
+    ws = torch.empty(ops.render_workspace_bytes(b, args.views, r, s), dtype=torch.uint8, device=dev)
     near, far = sc['near'], sc['far']
     field_args = (t['images'], t['features'], t['intrinsics'], t['extrinsics_inv'])
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]

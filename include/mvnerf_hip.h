@@ -84,12 +84,16 @@ int mvnerf_stratified_depths(const float* u, int n_rays, int n_samples, double n
  * acts_per_view (optional): (4, B*V, R, S, 128) and acts_fused (optional): (4, B, R, S, 128): the eight
  * activations the trunk returns with complete_output=True (layers.py:364-377): [x0, f1, f2, f3] per view and
  * [mean, u1, u2, u3] after the view mean; this is what LanguageNeRF consumes (lmvnerf/model_v4.py:261-262).
- * Arbitrary query points (not on rays): pass the points as rays_o, their directions as rays_d, z = 0, S = 1. */
+ * Arbitrary query points (not on rays): pass the points as rays_o, their directions as rays_d, z = 0, S = 1.
+ * workspace: 16-byte aligned device scratch of mvnerf_field_workspace_bytes(B,V,R) bytes. */
 int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, const float* images,
                       const float* features, const float* intrinsics, const float* extrinsics_inv,
                       const float* packed_net, int B, int V, int R, int S, int H, int W, float* rgbs,
                       int32_t* tap_idx, float* pix, float* embedding, float* acts_per_view, float* acts_fused,
-                      mvnerf_stream_t stream);
+                      void* workspace, mvnerf_stream_t stream);
+
+/* Bytes of scratch mvnerf_field_eval needs (B*V*R*128 floats: the per-(view, ray) part of layer 0). */
+size_t mvnerf_field_workspace_bytes(int B, int V, int R);
 
 /* MVVNeRFRenderer.volumetric_render (model_v0.py:89-100) with sigma_to_alpha (nerf_utils.py:129-140).
  * z (n_rays,S); rgbs (n_rays,S,4); S in {64,128,192,256}.
@@ -151,15 +155,15 @@ int mvnerf_readout(const float* embedding, const float* wr, const float* br, lon
 int mvnerf_finish_view(const float* rgb, const float* depth, long n, float* minmax_scratch, uint8_t* rgb8,
                        uint8_t* depth8, mvnerf_stream_t stream);
 
-/* Bytes of scratch mvnerf_render_fwd needs for (B,R,S). */
-size_t mvnerf_render_workspace_bytes(int B, int R, int S);
+/* Bytes of scratch mvnerf_render_fwd needs for (B,V,R,S). */
+size_t mvnerf_render_workspace_bytes(int B, int V, int R, int S);
 
 /* MVVNeRFRenderer._call (model_v0.py:113-184): stratified depths -> coarse field -> composite ->
  * resample -> fine field -> composite, all on `stream`, no host synchronisation.
  * u_coarse, u_fine (B,R,S) are the uniforms the reference draws inside the graph
  * (nerf_utils.py:57,151), here explicit.  S must be 64.
  * Outputs: rgb, fine_rgb (B,R,3); depth, fine_depth (B,R)  (the reference's 4-tuple, :184).
- * workspace: 16-byte aligned, mvnerf_render_workspace_bytes(B,R,S) bytes. */
+ * workspace: 16-byte aligned, mvnerf_render_workspace_bytes(B,V,R,S) bytes. */
 int mvnerf_render_fwd(const float* rays_o, const float* rays_d, const float* images, const float* features,
                       const float* intrinsics, const float* extrinsics_inv, const float* packed_coarse,
                       const float* packed_fine, const float* u_coarse, const float* u_fine, int B, int V,

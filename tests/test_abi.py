@@ -26,8 +26,9 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(lib, name), name
     assert lib.mvnerf_abi_version() == 1
-    assert lib.mvnerf_packed_net_floats() == 251528
-    assert lib.mvnerf_render_workspace_bytes(1, 4096, 64) == 16 * 64 * 4096 * 4
+    assert lib.mvnerf_packed_net_floats() == 251144
+    assert lib.mvnerf_render_workspace_bytes(1, 1, 4096, 64) == (16 * 64 + 128) * 4096 * 4
+    assert lib.mvnerf_field_workspace_bytes(2, 3, 10) == 2 * 3 * 10 * 128 * 4
 
 
 def test_argument_validation_without_gpu():
@@ -37,10 +38,11 @@ def test_argument_validation_without_gpu():
     one = ctypes.c_void_p(16)
     assert lib.mvnerf_composite(one, one, 4, 100, one, one, None, None) == -2          # S=100 unsupported
     assert lib.mvnerf_resample(one, one, one, 4, 32, 0, one, None, None, None, None) == -2
-    assert lib.mvnerf_field_eval(one, one, one, one, ctypes.c_void_p(20), one, one, one, 1, 1, 4, 64, 8, 8, one, None,
-                                 None, None, None, None, None) == -3                                 # misaligned features
-    assert lib.mvnerf_field_eval(one, one, one, one, one, one, one, one, 1, 1, 4, 64, 1, 8, one, None, None, None,
-                                 None, None, None) == -2                                             # H < 2
+    fe_tail = [one, None, None, None, None, None, one, None]   # rgbs, tap_idx, pix, embedding, acts x2, workspace, stream
+    assert lib.mvnerf_field_eval(one, one, one, one, ctypes.c_void_p(20), one, one, one, 1, 1, 4, 64, 8, 8, *fe_tail) == -3  # misaligned features
+    assert lib.mvnerf_field_eval(one, one, one, one, one, one, one, one, 1, 1, 4, 64, 1, 8, *fe_tail) == -2              # H < 2
+    fe_tail[6] = None
+    assert lib.mvnerf_field_eval(one, one, one, one, one, one, one, one, 1, 1, 4, 64, 8, 8, *fe_tail) == -1              # no workspace
     assert lib.mvnerf_sample_pdf(one, one, one, 4, 33, 64, 0, one, None, None, None) == -2  # only 63 bins is built
 
 

@@ -27,7 +27,8 @@ SIGNATURES = {
     'mvnerf_get_rays': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
     'mvnerf_stratified_depths': (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p]),
-    'mvnerf_field_eval': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p] * 7),
+    'mvnerf_field_eval': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p] * 8),
+    'mvnerf_field_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'mvnerf_composite': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mvnerf_resample': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
@@ -40,7 +41,7 @@ SIGNATURES = {
     'mvnerf_sample_pdf': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mvnerf_readout': (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     'mvnerf_finish_view': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'mvnerf_render_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'mvnerf_render_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'mvnerf_render_fwd': (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_double, c_double, c_int] + [c_void_p] * 6),
 }
 

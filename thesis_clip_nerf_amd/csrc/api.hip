@@ -30,11 +30,11 @@ int hip_status(hipError_t e, const char* what) {
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 struct Workspace {          // carve-up of the caller's scratch for mvnerf_render_fwd (floats)
-    float *z, *rgbs_c, *weights, *z_all, *rgbs_f;
+    float *z, *rgbs_c, *weights, *z_all, *rgbs_f, *dir_bias;
     size_t bytes;
 };
 
-Workspace carve(void* base, long n_rays, int S) {
+Workspace carve(void* base, long n_rays, int V, int S) {
     Workspace w;
     float* p = static_cast<float*>(base);
     const size_t n = (size_t)n_rays * S;
@@ -43,6 +43,7 @@ Workspace carve(void* base, long n_rays, int S) {
     w.z_all = p;        p += 2 * n;
     w.rgbs_c = p;       p += 4 * n;
     w.rgbs_f = p;       p += 8 * n;
+    w.dir_bias = p;     p += (size_t)n_rays * V * 128;
     w.bytes = (size_t)(p - static_cast<float*>(base)) * sizeof(float);
     return w;
 }
@@ -87,8 +88,8 @@ int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, 
                       const float* features, const float* intrinsics, const float* extrinsics_inv,
                       const float* packed_net, int B, int V, int R, int S, int H, int W, float* rgbs,
                       int32_t* tap_idx, float* pix, float* embedding, float* acts_per_view, float* acts_fused,
-                      mvnerf_stream_t stream) {
-    if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !packed_net || !rgbs)
+                      void* workspace, mvnerf_stream_t stream) {
+    if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !packed_net || !rgbs || !workspace)
         return fail(MVNERF_E_ARG, "mvnerf_field_eval: null pointer");
     if (B <= 0 || V <= 0 || R <= 0 || S <= 0) return fail(MVNERF_E_ARG, "mvnerf_field_eval: B=%d V=%d R=%d S=%d", B, V, R, S);
     if (H < 2 || W < 2) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval: source image %dx%d, need H,W >= 2 (bilinear taps)", H, W);
@@ -97,11 +98,11 @@ int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, 
         return fail(MVNERF_E_SHAPE, "mvnerf_field_eval: B*R*S=%ld or B*V*H*W too large for int32 indices", total);
     if (!aligned16(features) || !aligned16(packed_net) || !aligned16(rgbs) || (tap_idx && !aligned16(tap_idx)) ||
         (embedding && !aligned16(embedding)) || (acts_per_view && !aligned16(acts_per_view)) ||
-        (acts_fused && !aligned16(acts_fused)))
+        (acts_fused && !aligned16(acts_fused)) || !aligned16(workspace))
         return fail(MVNERF_E_ALIGN, "mvnerf_field_eval: features, packed_net, rgbs, tap_idx, embedding must be 16-byte aligned");
     mvnerf::FieldParams p;
     p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.images = images; p.features = features;
-    p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs; p.tap_idx = tap_idx; p.pix = pix; p.embedding = embedding; p.acts_view = acts_per_view; p.acts_fused = acts_fused;
+    p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs; p.tap_idx = tap_idx; p.pix = pix; p.embedding = embedding; p.acts_view = acts_per_view; p.acts_fused = acts_fused; p.dir_bias = static_cast<float*>(workspace);
     p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W;
     p.total = total;
     p.n_tiles = (total + 31) / 32;
@@ -205,9 +206,14 @@ int mvnerf_finish_view(const float* rgb, const float* depth, long n, float* minm
                       "mvnerf_finish_view");
 }
 
-size_t mvnerf_render_workspace_bytes(int B, int R, int S) {
-    if (B <= 0 || R <= 0 || S <= 0) return 0;
-    return carve(nullptr, (long)B * R, S).bytes;
+size_t mvnerf_field_workspace_bytes(int B, int V, int R) {
+    if (B <= 0 || V <= 0 || R <= 0) return 0;
+    return (size_t)B * V * R * 128 * sizeof(float);
+}
+
+size_t mvnerf_render_workspace_bytes(int B, int V, int R, int S) {
+    if (B <= 0 || V <= 0 || R <= 0 || S <= 0) return 0;
+    return carve(nullptr, (long)B * R, V, S).bytes;
 }
 
 int mvnerf_render_fwd(const float* rays_o, const float* rays_d, const float* images, const float* features,
@@ -222,17 +228,17 @@ int mvnerf_render_fwd(const float* rays_o, const float* rays_d, const float* ima
     if (!aligned16(workspace)) return fail(MVNERF_E_ALIGN, "mvnerf_render_fwd: workspace must be 16-byte aligned");
     const long n_rays = (long)B * R;
     if (n_rays * 2 * S >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_render_fwd: B*R*2S too large");
-    const Workspace w = carve(workspace, n_rays, S);
+    const Workspace w = carve(workspace, n_rays, V, S);
     int rc;
     if ((rc = mvnerf_stratified_depths(u_coarse, (int)n_rays, S, near_, far_, w.z, stream))) return rc;
     if ((rc = mvnerf_field_eval(rays_o, rays_d, w.z, images, features, intrinsics, extrinsics_inv, packed_coarse, B, V,
-                                R, S, H, W, w.rgbs_c, nullptr, nullptr, nullptr, nullptr, nullptr, stream)))
+                                R, S, H, W, w.rgbs_c, nullptr, nullptr, nullptr, nullptr, nullptr, w.dir_bias, stream)))
         return rc;
     if ((rc = mvnerf_composite(w.z, w.rgbs_c, (int)n_rays, S, rgb, depth, w.weights, stream))) return rc;
     if ((rc = mvnerf_resample(w.z, w.weights, u_fine, (int)n_rays, S, q7_mode, w.z_all, nullptr, nullptr, nullptr, stream)))
         return rc;
     if ((rc = mvnerf_field_eval(rays_o, rays_d, w.z_all, images, features, intrinsics, extrinsics_inv, packed_fine, B,
-                                V, R, 2 * S, H, W, w.rgbs_f, nullptr, nullptr, nullptr, nullptr, nullptr, stream)))
+                                V, R, 2 * S, H, W, w.rgbs_f, nullptr, nullptr, nullptr, nullptr, nullptr, w.dir_bias, stream)))
         return rc;
     return mvnerf_composite(w.z_all, w.rgbs_f, (int)n_rays, 2 * S, fine_rgb, fine_depth, nullptr, stream);
 }

@@ -250,80 +250,65 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? 1 : 
         float cam[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) cam[r] = row_dot4(E, r, wx, wy, wz, 1.0f);
-        // PE inputs of this lane: lower half-wave encodes cam xyz, upper half cam dir (Q3: w = 1)
-        const float in0 = h ? row_dot4(E, 0, dx, dy, dz, 1.0f) : cam[0];
-        const float in1 = h ? row_dot4(E, 1, dx, dy, dz, 1.0f) : cam[1];
-        const float in2 = h ? row_dot4(E, 2, dx, dy, dz, 1.0f) : cam[2];
         float pxl, pyl;
         pixel_from_cam(K, cam, &pxl, &pyl);
         const Taps tp = bilinear_taps(pxl, pyl, p.H, p.W);
         const int tl = (bv * p.H + tp.y0) * p.W + tp.x0;
+        const long vrow = ((long)bv * p.R + (ray - b * p.R)) * p.S + sidx;       // row in a (B*V,R,S,..) tensor
         if (valid && h == 0) {
-            const long q = ((long)bv * p.R + (ray - b * p.R)) * p.S + sidx;
             if (p.tap_idx) {
                 int4 t4 = make_int4(tl, tl + 1, tl + p.W, tl + p.W + 1);
-                *reinterpret_cast<int4*>(p.tap_idx + 4 * q) = t4;
+                *reinterpret_cast<int4*>(p.tap_idx + 4 * vrow) = t4;
             }
             if (p.pix) {
-                p.pix[2 * q + 0] = pxl;
-                p.pix[2 * q + 1] = pyl;
+                p.pix[2 * vrow + 0] = pxl;
+                p.pix[2 * vrow + 1] = pyl;
             }
         }
 
         // ---- layer 0: Dense 379 -> 128 on [PE(cam xyz) | PE(cam dir) | 2*rgb-1 | features] ----
-        bias_to_acc<false>(net + kPackB0, h, x);
-#pragma unroll 1
-        for (int d = 0; d < 3; ++d) {
-            const float xin = d == 0 ? in0 : (d == 1 ? in1 : in2);
-            float pe[20];
-#if MV_PE_RECUR
-            // fl32(x * fl32(pi*2^k)) == 2^k * fl32(x * fl32(pi)) exactly, so octave k is the k-fold double angle
-            // of octave 0.  Accurate sin/cos at k = 0 and k = 5, double-angle steps in between (error x16 at
-            // most: ~2e-6 absolute, against the 1e-4 bar; the op-level position_encoding stays fully accurate).
-            {
-                const float a0 = xin * 3.14159274101257324f;
+        // accumulator seed = b0 + W0_dir^T PE(cam dir) of this lane's (view, ray), from dir_bias_kernel
+        bias_to_acc<false>(p.dir_bias + 128 * ((long)bv * p.R + (ray - b * p.R)), h, x);
+        float pe[32];                                     // B operands of k-steps 0..31 (lower half sin, upper cos)
 #pragma unroll
-                for (int k = 0; k < kNFreq; ++k) {
-                    if (k == 0 || k == 5) {
-#if MV_ABL_PE
-                        pe[2 * k] = a0; pe[2 * k + 1] = a0 + 1.0f;
-#else
-                        sincos_f32(a0 * (float)(1 << k), &pe[2 * k], &pe[2 * k + 1]);
-#endif
-                    } else {
-                        const float sp = pe[2 * k - 2], cp = pe[2 * k - 1];
-                        pe[2 * k] = (sp + sp) * cp;                    // sin 2t = 2 sin t cos t
-                        pe[2 * k + 1] = fmaf(-(sp + sp), sp, 1.0f);    // cos 2t = 1 - 2 sin^2 t
-                    }
-                }
-            }
-#else
+        for (int d = 0; d < 3; ++d) {
+            const float a0 = cam[d] * 3.14159274101257324f;
+            float sk = 0.0f, ck = 0.0f;
 #pragma unroll
             for (int k = 0; k < kNFreq; ++k) {
-                const float arg = xin * (3.14159274101257324f * (float)(1 << k));   // fl32(pi)*2^k is exact
+                // fl32(x * fl32(pi*2^k)) == 2^k * fl32(x * fl32(pi)) exactly, so octave k is the k-fold double
+                // angle of octave 0.  Accurate sin/cos at k = 0 and k = 5, double-angle steps in between (error
+                // x16 at most: ~2e-6 absolute against the 1e-4 bar; the op-level position_encoding is exact).
+                if (!MV_PE_RECUR || k == 0 || k == 5) {
 #if MV_ABL_PE
-                pe[2 * k] = arg; pe[2 * k + 1] = arg + 1.0f;
+                    sk = a0; ck = a0 + 1.0f;
 #else
-                sincos_f32(arg, &pe[2 * k], &pe[2 * k + 1]);
+                    sincos_f32(a0 * (float)(1 << k), &sk, &ck);
 #endif
-            }
-#endif
-#pragma unroll
-            for (int gq = 0; gq < 5; ++gq) {
-                const float bb[4] = {pe[4 * gq], pe[4 * gq + 1], pe[4 * gq + 2], pe[4 * gq + 3]};
-                mfma_step(ws, bb, x);
+                } else {
+                    const float s2 = sk + sk;
+                    const float cn = fmaf(-s2, sk, 1.0f);              // cos 2t = 1 - 2 sin^2 t
+                    sk = s2 * ck;                                      // sin 2t = 2 sin t cos t
+                    ck = cn;
+                }
+                pe[d * 10 + k] = h ? ck : sk;
             }
         }
         {   // rgb taps of this lane's own sample, normalised 2*img-1 before the lerp (model_v0.py:120)
-            float bb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             const float* img = p.images + 3 * (long)tl;
+            float rgbv[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float a = img[c] * 2.0f - 1.0f, bq = img[3 + c] * 2.0f - 1.0f;
                 const float cq = img[3 * p.W + c] * 2.0f - 1.0f, dq = img[3 * p.W + 3 + c] * 2.0f - 1.0f;
-                const float val = bilerp(a, bq, cq, dq, tp.ax, tp.ay);
-                bb[c] = h ? 0.0f : val;
+                rgbv[c] = bilerp(a, bq, cq, dq, tp.ax, tp.ay);
             }
+            pe[30] = h ? rgbv[1] : rgbv[0];
+            pe[31] = h ? 0.0f : rgbv[2];
+        }
+#pragma unroll
+        for (int gq = 0; gq < 8; ++gq) {
+            const float bb[4] = {pe[4 * gq], pe[4 * gq + 1], pe[4 * gq + 2], pe[4 * gq + 3]};
             mfma_step(ws, bb, x);
         }
 #pragma unroll 1
@@ -362,7 +347,6 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? 1 : 
         }
 
         // ---- per-view feature blocks (layers.py:365-366); optional complete_output taps (:376-377) ----
-        const long vrow = ((long)bv * p.R + (ray - b * p.R)) * p.S + sidx;       // row in a (B*V,R,S,128) tensor
         const long vslot = (long)p.B * p.V * p.R * p.S * 128;
         if (p.acts_view && valid) store_acc(p.acts_view + 128 * vrow, h, x);
 #pragma unroll 1
@@ -431,6 +415,35 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? 1 : 
   }
 }
 
+// ---- per-(view, ray) layer-0 seed: b0 + W0[60:120]^T PE(cam dir)  (the direction is constant along a ray) ----
+// One wavefront per (b*V+v, ray).  Output in accumulator order [h][nb][r] so the field kernel loads it like a bias.
+__global__ __launch_bounds__(256) void dir_bias_kernel(FieldParams p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // over B*V*R
+    if (row >= (long)p.B * p.V * p.R) return;
+    const int bv = (int)(row / p.R);
+    const long ray = (long)(bv / p.V) * p.R + (row - (long)bv * p.R);
+    const float dx = p.rays_d[3 * ray + 0], dy = p.rays_d[3 * ray + 1], dz = p.rays_d[3 * ray + 2];
+    const float* E = p.einv + 16 * bv;
+    // lane m < 60 evaluates PE feature m = d*20 + 2k + f (nerf_utils.py:124 layout) of cam dir (Q3: w = 1)
+    const int m = lane < 60 ? lane : 59;
+    const int d = m / 20, k = (m % 20) >> 1, f = m & 1;
+    const float cd = row_dot4(E, d, dx, dy, dz, 1.0f);
+    float sv, cv;
+    sincos_f32(cd * (3.14159274101257324f * (float)(1 << k)), &sv, &cv);
+    const float mine = f ? cv : sv;
+    const float* wd = p.net + kPackW0Dir;
+    float a0 = p.net[kPackB0Plain + lane], a1 = p.net[kPackB0Plain + 64 + lane];
+    for (int mm = 0; mm < 60; ++mm) {
+        const float pv = __shfl(mine, mm);
+        a0 = fmaf(pv, wd[mm * 128 + lane], a0);
+        a1 = fmaf(pv, wd[mm * 128 + 64 + lane], a1);
+    }
+    float* out = p.dir_bias + 128 * row;
+    out[acc_slot(lane)] = a0;
+    out[acc_slot(64 + lane)] = a1;
+}
+
 // ---- weight packing -------------------------------------------------------------------------
 __global__ void pack_net_kernel(const float* __restrict__ src, float* __restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -441,9 +454,12 @@ __global__ void pack_net_kernel(const float* __restrict__ src, float* __restrict
     if (idx < kPackHidden) {                                          // layer-0 kernel
         const int G = idx / kGroupFloats, nb = (idx % kGroupFloats) / kChunkFloats;
         int row = -1;
-        if (G < kL0GroupRGB) row = (h ? 60 : 0) + 4 * G + e;
-        else if (G == kL0GroupRGB) row = (h == 0 && e < 3) ? 120 + e : -1;
-        else {
+        if (G < kL0GroupFeat) {
+            const int ks = 4 * G + e;
+            if (ks < 30) row = (ks / 10) * 20 + 2 * (ks % 10) + h;       // sin | cos of PE(xyz)
+            else if (ks == 30) row = 120 + h;                            // r | g
+            else row = h ? -1 : 122;                                     // b | 0
+        } else {
             const int q = G - kL0GroupFeat;
             row = 123 + 128 * (q / 16) + 8 * (q % 16) + 4 * h + e;
         }
@@ -471,6 +487,10 @@ __global__ void pack_net_kernel(const float* __restrict__ src, float* __restrict
         }
     } else if (idx < kPackBr + 4) {
         val = src[kKerasBr + (idx - kPackBr)];
+    } else if (idx >= kPackW0Dir && idx < kPackB0Plain) {             // plain W0 rows 60..119 (PE of cam dir)
+        val = src[kKerasW0 + 60 * kHidden + (idx - kPackW0Dir)];
+    } else if (idx >= kPackB0Plain) {
+        val = src[kKerasB0 + (idx - kPackB0Plain)];
     }
     dst[idx] = val;
 }
@@ -494,7 +514,9 @@ struct DeviceInfo {
     bool attr_set = false;
 };
 DeviceInfo g_dev[16];
+#if MV_PERSIST
 std::atomic<unsigned> g_launch_seq{0};
+#endif
 std::mutex g_dev_mutex;
 }  // namespace
 
@@ -524,6 +546,10 @@ hipError_t launch_field_eval(const FieldParams& p_in, hipStream_t stream) {
     p.tile_counter = di.counters + (g_launch_seq.fetch_add(1) % kCounterSlots);
     if ((e = hipMemsetAsync(p.tile_counter, 0, sizeof(unsigned int), stream)) != hipSuccess) return e;
 #endif
+    {
+        const long rows = (long)p.B * p.V * p.R;
+        hipLaunchKernelGGL(dir_bias_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
+    }
     const int waves = p.V > 1 ? 4 : MV_WAVES;
     const long want = (p.n_tiles + waves - 1) / waves;
     const long resident = (long)di.cus * (p.V > 1 ? 1 : 8 / MV_WAVES);   // workgroups that fit at once

@@ -16,6 +16,7 @@ struct FieldParams {
     const float* einv;
     const float* net;      // packed (mvnerf_pack.h)
     float* rgbs;
+    float* dir_bias;       // workspace (B*V*R,128): layer-0 accumulator seed per (view, ray)
     int32_t* tap_idx;      // optional
     float* pix;            // optional
     float* embedding;      // optional (B,R,S,128): trunk output before the read-out

@@ -16,29 +16,37 @@ namespace mvnerf {
 constexpr int kChunkFloats = 256;                       // 64 lanes x 4 floats = 1 KiB
 // The kernel consumes the chunks strictly in storage order ("weight stream"), four chunks (one
 // group x 4 output blocks, 4 KiB) per step, prefetching one step ahead across layer boundaries:
-//   layer 0   : 48 groups x 4 nb   (15 PE groups [h=0: xyz rows 0..59, h=1: dir rows 60..119],
-//                                   1 rgb group, 32 feature groups)
+//   layer 0   : 40 groups x 4 nb.  Groups 0..7 = 32 k-steps: k-step d*10+k carries PE(cam xyz) octave k of
+//               dimension d (h=0: sin row d*20+2k, h=1: cos row d*20+2k+1), k-steps 30,31 carry the rgb
+//               rows (120 | 121) and (122 | -).  Groups 8..39 = the 256 feature rows.
+//               The 60 PE(cam dir) rows are NOT streamed: cam dir is constant along a ray, so
+//               b0 + W0_dir^T PE(dir) is computed once per (view, ray) by dir_bias_kernel from the plain
+//               copy below and used as the layer-0 accumulator seed.
 //   12 hidden : 16 groups x 4 nb each, group = (kb, t)
 //   read-out  : 16 chunks (kb, t), output rows i >= 4 zero; consumed 4 chunks per step
-// followed by the biases in accumulator order [h][nb][r].
-constexpr int kL0Groups = 48;
-constexpr int kL0GroupPE = 0;
-constexpr int kL0GroupRGB = 15;
-constexpr int kL0GroupFeat = 16;
+// followed by the biases in accumulator order [h][nb][r], then plain copies of W0 rows 60..119 and b0.
+constexpr int kL0Groups = 40;
+constexpr int kL0GroupFeat = 8;
 constexpr int kGroupFloats = 4 * kChunkFloats;                         // 1024
 constexpr int kPackW0 = 0;
-constexpr int kPackW0Floats = kL0Groups * kGroupFloats;                // 49152
-constexpr int kPackHidden = kPackW0 + kPackW0Floats;                   // 49152
+constexpr int kPackW0Floats = kL0Groups * kGroupFloats;                // 40960
+constexpr int kPackHidden = kPackW0 + kPackW0Floats;
 constexpr int kHiddenWFloats = 16 * kGroupFloats;                      // 16384
 constexpr int kNumHidden = 12;                                         // 6 blocks x 2 Dense
-constexpr int kPackWr = kPackHidden + kNumHidden * kHiddenWFloats;     // 245760
+constexpr int kPackWr = kPackHidden + kNumHidden * kHiddenWFloats;
 constexpr int kPackWrFloats = 16 * kChunkFloats;                       // 4096
-constexpr int kPackB0 = kPackWr + kPackWrFloats;                       // 249856: bias perm [h][nb][r], 128
+constexpr int kPackB0 = kPackWr + kPackWrFloats;                       // bias perm [h][nb][r], 128
 constexpr int kPackBHidden = kPackB0 + 128;                            // 12 x 128
-constexpr int kPackBr = kPackBHidden + kNumHidden * 128;               // 251520
-constexpr int kPackTotal = kPackBr + 8;                                // 251528 (padded to 16 B multiple)
+constexpr int kPackBr = kPackBHidden + kNumHidden * 128;               // 4 (+4 pad)
+constexpr int kPackW0Dir = kPackBr + 8;                                // plain [60][128]: W0 rows 60..119
+constexpr int kPackB0Plain = kPackW0Dir + 60 * 128;                    // plain b0[128]
+constexpr int kPackTotal = kPackB0Plain + 128;                         // 251144 (multiple of 4)
 
 // feature index held by accumulator register r of lane-half h inside a 32-wide block
 __host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// inverse: position of feature n inside a 128-float vector stored in accumulator order [h][nb][r]
+__host__ __device__ constexpr int acc_slot(int n) {
+    return (((n & 31) >> 2) & 1) * 64 + (n >> 5) * 16 + ((n & 3) + 4 * ((n & 31) >> 3));
+}
 
 }  // namespace mvnerf

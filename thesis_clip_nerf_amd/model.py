@@ -108,7 +108,7 @@ class MVVNeRFRenderer:
             raise ValueError(f'ray_origins: shape {tuple(rays_o.shape)}, expected ({batch_size}, {n_rays}, 3)')
         u_coarse, u_fine = self._uniforms(batch_size, n_rays, u_coarse, u_fine, generator)
         pc, pf = self.packed()
-        need = ops.render_workspace_bytes(batch_size, n_rays, self.n_samples)
+        need = ops.render_workspace_bytes(batch_size, images.shape[1], n_rays, self.n_samples)
         if self._workspace is None or self._workspace.numel() < need:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         return ops.render_fwd(rays_o, rays_d, images, features, k4, einv, pc, pf, self._dev(u_coarse), self._dev(u_fine),

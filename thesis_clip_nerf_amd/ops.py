@@ -106,10 +106,11 @@ def field_eval(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, 
     emb = torch.empty((b, r, s, 128), dtype=torch.float32, device=dev) if return_embedding else None
     acts_v = torch.empty((4, b * v, r, s, 128), dtype=torch.float32, device=dev) if complete_output else None
     acts_f = torch.empty((4, b, r, s, 128), dtype=torch.float32, device=dev) if complete_output else None
+    ws = torch.empty(int(_lib.lib().mvnerf_field_workspace_bytes(b, v, r)), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = _lib.lib().mvnerf_field_eval(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(intrinsics),
                                           _p(extrinsics_inv), _p(packed_net), b, v, r, s, h, w, _p(rgbs), _p(taps),
-                                          _p(pix), _p(emb), _p(acts_v), _p(acts_f), _stream(rays_o))
+                                          _p(pix), _p(emb), _p(acts_v), _p(acts_f), _p(ws), _stream(rays_o))
     _lib.check(rc, 'field_eval')
     out = (rgbs,)
     if return_taps:
@@ -171,8 +172,8 @@ def resample(z, weights, u_fine, q7_mode=Q7_ZERO, return_aux=False):
     return (z_all, z_fine, above, below) if return_aux else z_all
 
 
-def render_workspace_bytes(b, r, s):
-    return int(_lib.lib().mvnerf_render_workspace_bytes(int(b), int(r), int(s)))
+def render_workspace_bytes(b, v, r, s):
+    return int(_lib.lib().mvnerf_render_workspace_bytes(int(b), int(v), int(r), int(s)))
 
 
 def render_fwd(rays_o, rays_d, images, features, intrinsics, extrinsics_inv, packed_coarse, packed_fine, u_coarse,
@@ -192,7 +193,7 @@ def render_fwd(rays_o, rays_d, images, features, intrinsics, extrinsics_inv, pac
     _chk(packed_coarse, 'packed_coarse', shape=(packed_net_floats(),))
     _chk(packed_fine, 'packed_fine', shape=(packed_net_floats(),))
     dev = rays_o.device
-    need = render_workspace_bytes(b, r, s)
+    need = render_workspace_bytes(b, v, r, s)
     if workspace is None:
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)
     else:
