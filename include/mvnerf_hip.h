@@ -155,6 +155,47 @@ int mvnerf_readout(const float* embedding, const float* wr, const float* br, lon
 int mvnerf_finish_view(const float* rgb, const float* depth, long n, float* minmax_scratch, uint8_t* rgb8,
                        uint8_t* depth8, mvnerf_stream_t stream);
 
+/* ---- training step (MVVNeRFRenderer.train_step, model_v0.py:186-197; optimize, nerf_utils.py:8-12) ----
+ * Gradient scope of this version: every MLP variable, with the fine-pass sample depths held constant (no
+ * gradient through sample_pdf / sort / sample positions); single source view (V = 1). */
+
+/* Bytes of the activation stash one mvnerf_field_eval_stash call writes (13 pre-activation tensors, tile layout). */
+size_t mvnerf_stash_bytes(int B, int R, int S);
+/* Bytes of scratch mvnerf_field_backward needs. */
+size_t mvnerf_field_backward_scratch_bytes(int B, int R, int S);
+
+/* mvnerf_field_eval in training mode: also stores the trunk's pre-activations into `stash`. */
+int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                            const float* features, const float* intrinsics, const float* extrinsics_inv,
+                            const float* packed_net, int B, int V, int R, int S, int H, int W, float* rgbs, float* stash,
+                            void* workspace, mvnerf_stream_t stream);
+
+/* The 12 hidden Dense kernels of one MLP, transposed, in weight-stream order (12 x 16384 floats), for the
+ * dX GEMMs of the backward pass.  net_keras: 247300 floats (see mvnerf_pack_net). */
+int mvnerf_pack_bwd_streams(const float* net_keras, float* bwd_streams, mvnerf_stream_t stream);
+
+/* d pred = 2 (pred - label) / n and *loss += mean((pred - label)^2) (Keras MeanSquaredError, model_v0.py:193). */
+int mvnerf_mse_grad(const float* pred, const float* label, long n, float* d_pred, float* loss, mvnerf_stream_t stream);
+
+/* volumetric_render backward (model_v0.py:89-100): d_rgb (n_rays,3), d_depth (optional, n_rays), d_weights
+ * (optional, n_rays x S) -> d_rgbs (n_rays,S,4) = gradient w.r.t. the per-sample (r,g,b,sigma).  S in {64,128}. */
+int mvnerf_composite_bwd(const float* z, const float* rgbs, const float* d_rgb, const float* d_depth,
+                         const float* d_weights, int n_rays, int S, float* d_rgbs, mvnerf_stream_t stream);
+
+/* Backward of one mvnerf_field_eval_stash call: accumulates dL/d(net variables) into `grad` (247300 floats, Keras
+ * order, caller zeroes it) given d_rgbs (B,R,S,4).  Inputs as in the forward call, plus net_keras, the
+ * transposed streams and the stash. */
+int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                          const float* features, const float* intrinsics, const float* extrinsics_inv,
+                          const float* net_keras, const float* bwd_streams, const float* stash, const float* rgbs,
+                          const float* d_rgbs, int B, int V, int R, int S, int H, int W, void* scratch, float* grad,
+                          mvnerf_stream_t stream);
+
+/* optimize(): clip-by-value (clip > 0) then one Adam step with the bias-corrected rate lr_t.
+ * update_mask (optional): n bytes, 0 = leave the element untouched. */
+int mvnerf_adam_clip(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1, float beta2,
+                     float eps, float clip, const unsigned char* update_mask, mvnerf_stream_t stream);
+
 /* Bytes of scratch mvnerf_render_fwd needs for (B,V,R,S). */
 size_t mvnerf_render_workspace_bytes(int B, int V, int R, int S);
 

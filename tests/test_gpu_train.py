@@ -1,0 +1,97 @@
+"""Training step on the GPU (model_v0.py:186-197) vs the differentiable torch oracle.
+Gradient scope under test: every MLP variable with the fine-pass depths held constant
+(`stop_fine_z=True` in the oracle) - the variant this round's backward implements."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mvnerf_oracle as O
+from oracle import mvnerf_torch as T
+from thesis_clip_nerf_amd import MVVNeRFRenderer, ops
+from thesis_clip_nerf_amd.synthetic import make_scene
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_composite_bwd_matches_autograd():
+    rng = np.random.default_rng(0)
+    for s in (64, 128):
+        z = np.sort(rng.uniform(0.3, 1.3, (1, 7, s)), -1).astype(np.float32)
+        rgbs = rng.random((1, 7, s, 4)).astype(np.float32)
+        rgbs[..., 3] = (rgbs[..., 3] * 30 - 3)                         # some negative densities (relu branch)
+        g_rgb = rng.standard_normal((1, 7, 3)).astype(np.float32)
+        g_depth = rng.standard_normal((1, 7)).astype(np.float32)
+        g_w = rng.standard_normal((1, 7, s)).astype(np.float32)
+        tz = torch.tensor(z, dtype=torch.float64)
+        tr = torch.tensor(rgbs, dtype=torch.float64, requires_grad=True)
+        rgb, depth, w = T.volumetric_render(tz, tr[..., 3], tr[..., :3])
+        (rgb * torch.tensor(g_rgb) + 0).sum().add((depth * torch.tensor(g_depth)).sum()).add((w * torch.tensor(g_w)).sum()).backward()
+        got = ops.composite_bwd(dev(z), dev(rgbs), dev(g_rgb), dev(g_depth), dev(g_w)).cpu().numpy()
+        ref = tr.grad.numpy()
+        assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_adam_clip_matches_keras_formula():
+    rng = np.random.default_rng(1)
+    n = 1000
+    p0 = rng.standard_normal(n).astype(np.float32)
+    g = (rng.standard_normal(n) * 3).astype(np.float32)
+    p, m, v = dev(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    mask = torch.ones(n, dtype=torch.uint8, device=DEV)
+    mask[::7] = 0
+    pr, mr, vr = p0.astype(np.float64), np.zeros(n), np.zeros(n)
+    for step in (1, 2, 3):
+        lr_t = 1e-3 * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        ops.adam_clip(p, dev(g), m, v, lr_t, clip=1.0, update_mask=mask)
+        gc = np.clip(g, -1, 1).astype(np.float64)
+        mr = 0.9 * mr + 0.1 * gc
+        vr = 0.999 * vr + 0.001 * gc * gc
+        upd = pr - lr_t * mr / (np.sqrt(vr) + 1e-7)
+        pr = np.where(mask.cpu().numpy() > 0, upd, pr)
+    assert np.abs(p.cpu().numpy() - pr).max() < 1e-6
+    assert np.array_equal(p.cpu().numpy()[::7], p0[::7])
+
+
+@pytest.mark.parametrize('batch', [1, 2])
+def test_loss_and_grads_match_torch_oracle(batch):
+    sc = make_scene(seed=40 + batch, batch=batch, n_views=1, height=16, width=16, n_rays=24, bias_scale=0.05)
+    y = np.random.default_rng(2).random((batch, 24, 3)).astype(np.float32)
+    loss_ref, gc_ref, gf_ref, outs = T.train_loss_and_grads(sc['coarse'], sc['fine'], y, sc, dtype=torch.float64, stop_fine_z=True)
+    m = MVVNeRFRenderer(24, 24, n_views=1, batch_size=batch, near=sc['near'], far=sc['far'], device=DEV)
+    m.set_weights(sc['coarse'], sc['fine'])
+    inputs = tuple(sc[k] for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'])
+    loss, grad, out = m.loss_and_grads(inputs, y, sc['features'], u_coarse=dev(sc['u_coarse']), u_fine=dev(sc['u_fine']))
+    torch.cuda.synchronize()
+    assert abs(float(loss) - loss_ref) < 1e-5
+    for g, r in zip(out, outs):
+        assert np.abs(g.cpu().numpy() - r).max() < 1e-4
+    grad = grad.cpu().numpy()
+    for name, got, ref in (('coarse', grad[:247300], gc_ref), ('fine', grad[247300:], gf_ref)):
+        # fp32 kernels vs the fp64 oracle: besides rounding, a pre-activation within ~1e-6 of zero may take the other
+        # relu branch, which moves individual entries by one sample's contribution; hence an L2 bar per section
+        # (so a wrong small section cannot hide behind a large one) plus a loose max-abs bar.
+        for lo, hi in ((0, 48512), (48512, 48640), (48640, 246784), (246784, 247300)):
+            r, g = ref[lo:hi], got[lo:hi]
+            assert np.linalg.norm(g - r) < 2e-3 * np.linalg.norm(r) + 1e-9, (name, lo, hi, np.linalg.norm(g - r) / np.linalg.norm(r))
+            assert np.abs(g - r).max() < 1e-2 * np.abs(r).max() + 1e-9, (name, lo, hi)
+        print(name, 'rel L2 grad error', np.linalg.norm(got - ref) / np.linalg.norm(ref))
+
+
+def test_train_step_reduces_loss_and_respects_q9():
+    sc = make_scene(seed=50, batch=1, n_views=1, height=16, width=16, n_rays=64, bias_scale=0.0)
+    y = np.random.default_rng(3).random((1, 64, 3)).astype(np.float32)
+    m = MVVNeRFRenderer(64, 64, n_views=1, batch_size=1, near=sc['near'], far=sc['far'], device=DEV)
+    m.set_weights(sc['coarse'], sc['fine'])
+    m.compile(learning_rate=1e-3)
+    data = (tuple(sc[k] for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv']), y)
+    uc, uf = dev(sc['u_coarse']), dev(sc['u_fine'])
+    readout_before = m.coarse_net[-516:].clone()
+    losses = [float(m.train_step(data, combined_features=sc['features'], u_coarse=uc, u_fine=uf)['loss']) for _ in range(8)]
+    assert losses[-1] < losses[0], losses
+    assert torch.equal(m.coarse_net[-516:], readout_before)           # RenderReadout is not in the optimizer list (Q9)
+    assert not torch.equal(m.coarse_net[:100], dev(sc['coarse'])[:100])

@@ -102,7 +102,7 @@ int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, 
         return fail(MVNERF_E_ALIGN, "mvnerf_field_eval: features, packed_net, rgbs, tap_idx, embedding must be 16-byte aligned");
     mvnerf::FieldParams p;
     p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.images = images; p.features = features;
-    p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs; p.tap_idx = tap_idx; p.pix = pix; p.embedding = embedding; p.acts_view = acts_per_view; p.acts_fused = acts_fused; p.dir_bias = static_cast<float*>(workspace);
+    p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs; p.tap_idx = tap_idx; p.pix = pix; p.embedding = embedding; p.acts_view = acts_per_view; p.acts_fused = acts_fused; p.dir_bias = static_cast<float*>(workspace); p.stash = nullptr; p.stash_stride = 0;
     p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W;
     p.total = total;
     p.n_tiles = (total + 31) / 32;
@@ -204,6 +204,135 @@ int mvnerf_finish_view(const float* rgb, const float* depth, long n, float* minm
     if (n <= 0) return fail(MVNERF_E_ARG, "mvnerf_finish_view: n=%ld", n);
     return hip_status(mvnerf::launch_finish_view(rgb, depth, n, minmax_scratch, rgb8, depth8, static_cast<hipStream_t>(stream)),
                       "mvnerf_finish_view");
+}
+
+// ---- training --------------------------------------------------------------------------------------------
+namespace {
+long tiles_for(int B, int R, int S) { return ((long)B * R * S + 31) / 32; }
+constexpr int kBwdMaxWGs = 512;      // resident workgroups of the dW kernels (2 per CU)
+}  // namespace
+
+size_t mvnerf_stash_bytes(int B, int R, int S) {
+    if (B <= 0 || R <= 0 || S <= 0) return 0;
+    return (size_t)13 * tiles_for(B, R, S) * 128 * 32 * sizeof(float);
+}
+
+size_t mvnerf_field_backward_scratch_bytes(int B, int R, int S) {
+    if (B <= 0 || R <= 0 || S <= 0) return 0;
+    return (size_t)tiles_for(B, R, S) * (3 * 128 + 32) * 32 * sizeof(float);
+}
+
+int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                            const float* features, const float* intrinsics, const float* extrinsics_inv,
+                            const float* packed_net, int B, int V, int R, int S, int H, int W, float* rgbs, float* stash,
+                            void* workspace, mvnerf_stream_t stream) {
+    if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !packed_net || !rgbs || !stash || !workspace)
+        return fail(MVNERF_E_ARG, "mvnerf_field_eval_stash: null pointer");
+    if (V != 1) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_stash: V=%d, the training path is built for one source view", V);
+    if (B <= 0 || R <= 0 || S <= 0 || H < 2 || W < 2) return fail(MVNERF_E_ARG, "mvnerf_field_eval_stash: B=%d R=%d S=%d H=%d W=%d", B, R, S, H, W);
+    const long total = (long)B * R * S;
+    if (total >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_stash: B*R*S too large");
+    if (!aligned16(features) || !aligned16(packed_net) || !aligned16(rgbs) || !aligned16(stash) || !aligned16(workspace))
+        return fail(MVNERF_E_ALIGN, "mvnerf_field_eval_stash: features, packed_net, rgbs, stash, workspace must be 16-byte aligned");
+    mvnerf::FieldParams p = {};
+    p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.images = images; p.features = features;
+    p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs;
+    p.dir_bias = static_cast<float*>(workspace);
+    p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W;
+    p.total = total;
+    p.n_tiles = (total + 31) / 32;
+    p.stash = stash;
+    p.stash_stride = p.n_tiles * 128 * 32;
+    return hip_status(mvnerf::launch_field_eval(p, static_cast<hipStream_t>(stream)), "mvnerf_field_eval_stash");
+}
+
+int mvnerf_pack_bwd_streams(const float* net_keras, float* bwd_streams, mvnerf_stream_t stream) {
+    if (!net_keras || !bwd_streams) return fail(MVNERF_E_ARG, "mvnerf_pack_bwd_streams: null pointer");
+    if (!aligned16(bwd_streams)) return fail(MVNERF_E_ALIGN, "mvnerf_pack_bwd_streams: bwd_streams must be 16-byte aligned");
+    for (int l = 0; l < 12; ++l) {
+        const float* src = net_keras + mvnerf::kKerasBlocks + (l / 2) * mvnerf::kKerasBlockStride +
+                           (l % 2) * (mvnerf::kHidden * mvnerf::kHidden + mvnerf::kHidden);
+        const hipError_t e = mvnerf::launch_pack_dense(src, 1, bwd_streams + (size_t)l * mvnerf::kHiddenWFloats,
+                                                       static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return hip_status(e, "mvnerf_pack_bwd_streams");
+    }
+    return 0;
+}
+
+int mvnerf_mse_grad(const float* pred, const float* label, long n, float* d_pred, float* loss, mvnerf_stream_t stream) {
+    if (!pred || !label || !d_pred || !loss) return fail(MVNERF_E_ARG, "mvnerf_mse_grad: null pointer");
+    if (n <= 0) return fail(MVNERF_E_ARG, "mvnerf_mse_grad: n=%ld", n);
+    return hip_status(mvnerf::launch_mse_grad(pred, label, n, d_pred, loss, static_cast<hipStream_t>(stream)), "mvnerf_mse_grad");
+}
+
+int mvnerf_composite_bwd(const float* z, const float* rgbs, const float* d_rgb, const float* d_depth,
+                         const float* d_weights, int n_rays, int S, float* d_rgbs, mvnerf_stream_t stream) {
+    if (!z || !rgbs || !d_rgb || !d_rgbs) return fail(MVNERF_E_ARG, "mvnerf_composite_bwd: null pointer");
+    if (n_rays <= 0) return fail(MVNERF_E_ARG, "mvnerf_composite_bwd: n_rays=%d", n_rays);
+    if (S != 64 && S != 128) return fail(MVNERF_E_SHAPE, "mvnerf_composite_bwd: S=%d, supported: 64, 128", S);
+    if (!aligned16(rgbs) || !aligned16(d_rgbs)) return fail(MVNERF_E_ALIGN, "mvnerf_composite_bwd: rgbs, d_rgbs must be 16-byte aligned");
+    return hip_status(mvnerf::launch_composite_bwd(z, rgbs, d_rgb, d_depth, d_weights, n_rays, S, d_rgbs,
+                                                   static_cast<hipStream_t>(stream)),
+                      "mvnerf_composite_bwd");
+}
+
+int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                          const float* features, const float* intrinsics, const float* extrinsics_inv,
+                          const float* net_keras, const float* bwd_streams, const float* stash, const float* rgbs,
+                          const float* d_rgbs, int B, int V, int R, int S, int H, int W, void* scratch, float* grad,
+                          mvnerf_stream_t stream) {
+    using namespace mvnerf;
+    if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !net_keras || !bwd_streams ||
+        !stash || !rgbs || !d_rgbs || !scratch || !grad)
+        return fail(MVNERF_E_ARG, "mvnerf_field_backward: null pointer");
+    if (V != 1) return fail(MVNERF_E_SHAPE, "mvnerf_field_backward: V=%d, the training path is built for one source view", V);
+    if (B <= 0 || R <= 0 || S <= 0 || H < 2 || W < 2) return fail(MVNERF_E_ARG, "mvnerf_field_backward: bad sizes");
+    if (!aligned16(net_keras) || !aligned16(bwd_streams) || !aligned16(stash) || !aligned16(rgbs) || !aligned16(d_rgbs) || !aligned16(scratch))
+        return fail(MVNERF_E_ALIGN, "mvnerf_field_backward: net_keras, bwd_streams, stash, rgbs, d_rgbs, scratch must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long total = (long)B * R * S, n_tiles = (total + 31) / 32;
+    const size_t slot = (size_t)n_tiles * 128 * 32;
+    float* buf[3] = {static_cast<float*>(scratch), static_cast<float*>(scratch) + slot, static_cast<float*>(scratch) + 2 * slot};
+    float* do_tl = static_cast<float*>(scratch) + 3 * slot;
+    auto stash_slot = [&](int s) { return stash + (size_t)s * slot; };
+    hipError_t e;
+#define MV_TRY(call) if ((e = (call)) != hipSuccess) return hip_status(e, "mvnerf_field_backward")
+    // read-out
+    MV_TRY(launch_readout_bwd(stash_slot(12), rgbs, d_rgbs, net_keras + kKerasWr, total, n_tiles, do_tl, buf[0], st));
+    MV_TRY(launch_dw_tile(stash_slot(12), 1, do_tl, 32, n_tiles, grad + kKerasWr, 4, 4, grad + kKerasBr, kBwdMaxWGs, st));
+    int g = 0;                                         // buf[g] holds dL/d(block output)
+    for (int bi = 5; bi >= 0; --bi) {
+        float* gb = grad + kKerasBlocks + bi * kKerasBlockStride;
+        const int dh = (g + 1) % 3, gn = (g + 2) % 3;
+        // second Dense of the block: out = x_in + W2^T relu(hid) + b2
+        MV_TRY(launch_dw_tile(stash_slot(2 * bi + 1), 1, buf[g], 128, n_tiles, gb + kHidden * kHidden + kHidden, kHidden, kHidden,
+                              gb + 2 * kHidden * kHidden + kHidden, kBwdMaxWGs, st));
+        MV_TRY(launch_dense_tile(buf[g], bwd_streams + (size_t)(2 * bi + 1) * kHiddenWFloats, stash_slot(2 * bi + 1), nullptr,
+                                 buf[dh], n_tiles, st));
+        // first Dense: hid = W1^T relu(x_in) + b1 ; the identity branch adds dL/d(out) back
+        MV_TRY(launch_dw_tile(stash_slot(2 * bi), 1, buf[dh], 128, n_tiles, gb, kHidden, kHidden, gb + kHidden * kHidden,
+                              kBwdMaxWGs, st));
+        MV_TRY(launch_dense_tile(buf[dh], bwd_streams + (size_t)(2 * bi) * kHiddenWFloats, stash_slot(2 * bi), buf[g], buf[gn],
+                                 n_tiles, st));
+        g = gn;
+    }
+    // layer 0 (inputs recomputed)
+    FieldParams p = {};
+    p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.images = images; p.features = features;
+    p.k4 = intrinsics; p.einv = extrinsics_inv;
+    p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W; p.total = total; p.n_tiles = n_tiles;
+    MV_TRY(launch_dw0(p, buf[g], grad + kKerasW0, grad + kKerasB0, kBwdMaxWGs, st));
+#undef MV_TRY
+    return 0;
+}
+
+int mvnerf_adam_clip(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1, float beta2,
+                     float eps, float clip, const unsigned char* update_mask, mvnerf_stream_t stream) {
+    if (!param || !grad || !m || !v) return fail(MVNERF_E_ARG, "mvnerf_adam_clip: null pointer");
+    if (n <= 0) return fail(MVNERF_E_ARG, "mvnerf_adam_clip: n=%ld", n);
+    return hip_status(mvnerf::launch_adam_clip(param, grad, m, v, n, lr_t, beta1, beta2, eps, clip, update_mask,
+                                               static_cast<hipStream_t>(stream)),
+                      "mvnerf_adam_clip");
 }
 
 size_t mvnerf_field_workspace_bytes(int B, int V, int R) {

@@ -18,8 +18,6 @@
 
 namespace mvnerf {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kTile = 32;            // samples per wavefront (MFMA N dimension)
 // Launch shape: measured best ("Field kernel: what was measured") is the plain one: one
@@ -62,81 +60,9 @@ constexpr int kStageRow = 128;       // floats per staged sample row (half of th
 #define MV_WAVES 4         // waves per workgroup of the single-view kernel (4 or 8)
 #endif
 
-__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// relu as one v_med3_f32 (fmaxf lowers to a canonicalising v_max pair in front of every MFMA)
-__device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
-
-// relu of the 4 B operands of a step as four single v_max_f32 (fmaxf lowers to a canonicalising
-// v_max pair + s_nop in front of every MFMA).  The trailing s_nop 1 covers the VALU-write ->
-// MFMA-read wait states for the compiler-scheduled MFMAs that consume the outputs.
-__device__ __forceinline__ void relu4(const float (&in)[4], float (&b)[4]) {
-#if MV_ASM_RELU
-    asm("v_max_f32_e32 %0, 0, %4\n\tv_max_f32_e32 %1, 0, %5\n\tv_max_f32_e32 %2, 0, %6\n\tv_max_f32_e32 %3, 0, %7\n\ts_nop 1"
-        : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
-        : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]));
-#else
-#pragma unroll
-    for (int e = 0; e < 4; ++e) b[e] = fmaxf(in[e], 0.0f);
-#endif
-}
-
-// The weight stream: `cur` holds the 4 chunks (4 KiB per wave) of the step being consumed, `next`
-// points at this lane's 16 bytes of the following step.  Every step first issues the loads of the
-// following step, then runs its 16 MFMAs (1024 cycles of matrix pipe), so an L2 round trip is
-// always covered, also across layer boundaries (the chunks of all layers are contiguous).
-struct WStream {
-    __amdgpu_buffer_rsrc_t rsrc;   // buffer descriptor of the packed net (SGPRs)
-    int voff;                      // lane * 16
-    int pos;                       // wave-uniform byte offset of the NEXT step (SGPR)
-    f32x4 cur[4];
-};
-
-// buffer_load_dwordx4 v, voff, rsrc, pos offen offset:imm -- the uniform stream position rides in the
-// scalar offset and the chunk index in the immediate, so a step costs no VALU address arithmetic.
-template <int kImm>
-__device__ __forceinline__ f32x4 ws_load(const WStream& ws, int pos) {
-    using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
-    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff + kImm, pos, 0);
-    return __builtin_bit_cast(f32x4, r);
-}
-
-__device__ __forceinline__ void ws_begin(WStream& ws, const float* net, int lane) {
-    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(net), 0, kPackTotal * 4, 0x00020000);
-    ws.voff = lane * 16;
-    ws.cur[0] = ws_load<0>(ws, 0);
-    ws.cur[1] = ws_load<1024>(ws, 0);
-    ws.cur[2] = ws_load<2048>(ws, 0);
-    ws.cur[3] = ws_load<3072>(ws, 0);
-    ws.pos = 4096;
-}
-
-// One step = 4 k-steps x 4 output blocks: acc[nb] += A(cur[nb])[e] x b[e]
-__device__ __forceinline__ void mfma_step(WStream& ws, const float (&b)[4], f32x16 (&acc)[4]) {
-#if MV_ABL_WLOAD
-    const f32x4 n0 = ws.cur[1], n1 = ws.cur[2], n2 = ws.cur[3], n3 = ws.cur[0];
-#else
-    const f32x4 n0 = ws_load<0>(ws, ws.pos), n1 = ws_load<1024>(ws, ws.pos), n2 = ws_load<2048>(ws, ws.pos),
-                n3 = ws_load<3072>(ws, ws.pos);
-#endif
-#if MV_PIN_LOADS
-    __builtin_amdgcn_sched_barrier(0);      // keep the prefetch a full step ahead of its use
-#endif
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        acc[0] = mfma(ws.cur[0][e], b[e], acc[0]);
-        acc[1] = mfma(ws.cur[1][e], b[e], acc[1]);
-        acc[2] = mfma(ws.cur[2][e], b[e], acc[2]);
-        acc[3] = mfma(ws.cur[3][e], b[e], acc[3]);
-    }
-    ws.cur[0] = n0;
-    ws.cur[1] = n1;
-    ws.cur[2] = n2;
-    ws.cur[3] = n3;
-    ws.pos += 4096;
-}
+}  // namespace mvnerf
+#include "mvnerf_mfma.h"
+namespace mvnerf {
 
 template <bool kAdd>
 __device__ __forceinline__ void bias_to_acc(const float* __restrict__ bperm, int h, f32x16 (&acc)[4]) {
@@ -179,12 +105,18 @@ __device__ __forceinline__ void dense128(WStream& ws, const f32x16 (&in)[4], f32
 }
 
 // x <- x + W2^T relu(W1^T relu(x) + b1) + b2    (ResNetMLPBlock.call, layers.py:284-298)
+// Training mode: `stash` (may be null) receives the two pre-activation tensors of the block in tile layout
+// (slot 0: hid = input of the second Dense, slot 1: block output = input of the next layer).
+template <bool kStash>
 __device__ __forceinline__ void resnet_block(WStream& ws, const float* __restrict__ bias1, int h, f32x16 (&x)[4],
-                                             f32x16 (&hid)[4]) {
+                                             f32x16 (&hid)[4], float* __restrict__ stash, long slot_stride, long tile,
+                                             int j) {
     bias_to_acc<false>(bias1, h, hid);
     dense128(ws, x, hid);
+    if (kStash) store_tl(stash, tile, j, h, hid);
     bias_to_acc<true>(bias1 + 128, h, x);
     dense128(ws, hid, x);
+    if (kStash) store_tl(stash + slot_stride, tile, j, h, x);
 }
 
 // lane (j,h) holds features 32*nb + 8*q + 4*h + {0..3} of sample j in registers 4q..4q+3 of block nb
@@ -203,8 +135,8 @@ __device__ __forceinline__ int stage_offset(int row, int chunk) {      // floats
     return row * kStageRow + ((chunk ^ (row & 15)) << 2);
 }
 
-template <bool kMultiView>
-__global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? 1 : 2) void field_eval_kernel(FieldParams p) {
+template <bool kMultiView, bool kStash>
+__global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, (kMultiView || kStash) ? 1 : 2) void field_eval_kernel(FieldParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];       // 16 KiB per wave
 
     const int lane = threadIdx.x & 63;
@@ -243,7 +175,7 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? 1 : 
     WStream ws;
 
     for (int v = 0; v < p.V; ++v) {
-        ws_begin(ws, net, lane);                         // layer-0 group 0 (re-read per view)
+        ws_begin(ws, net, kPackTotal * 4, lane);                         // layer-0 group 0 (re-read per view)
         const int bv = b * p.V + v;
         const float* E = p.einv + 16 * bv;
         const float* K = p.k4 + 16 * bv;
@@ -346,12 +278,14 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? 1 : 
             }
         }
 
+        if (kStash) store_tl(p.stash, tile, j, h, x);        // slot 0: layer-0 output (training mode, V = 1)
         // ---- per-view feature blocks (layers.py:365-366); optional complete_output taps (:376-377) ----
         const long vslot = (long)p.B * p.V * p.R * p.S * 128;
         if (p.acts_view && valid) store_acc(p.acts_view + 128 * vrow, h, x);
 #pragma unroll 1
         for (int bi = 0; bi < 3; ++bi) {
-            resnet_block(ws, net + kPackBHidden + 256 * bi, h, x, hid);
+            resnet_block<kStash>(ws, net + kPackBHidden + 256 * bi, h, x, hid,
+                                 kStash ? p.stash + (1 + 2 * bi) * p.stash_stride : nullptr, p.stash_stride, tile, j);
             if (p.acts_view && valid) store_acc(p.acts_view + (bi + 1) * vslot + 128 * vrow, h, x);
         }
 
@@ -370,7 +304,8 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? 1 : 
     if (p.acts_fused && valid) store_acc(p.acts_fused + 128 * g, h, x);           // the view mean
 #pragma unroll 1
     for (int bi = 3; bi < 6; ++bi) {
-        resnet_block(ws, net + kPackBHidden + 256 * bi, h, x, hid);
+        resnet_block<kStash>(ws, net + kPackBHidden + 256 * bi, h, x, hid,
+                             kStash ? p.stash + (1 + 2 * bi) * p.stash_stride : nullptr, p.stash_stride, tile, j);
         if (p.acts_fused && valid) store_acc(p.acts_fused + (bi - 2) * p.total * 128 + 128 * g, h, x);
     }
 
@@ -533,9 +468,9 @@ hipError_t launch_field_eval(const FieldParams& p_in, hipStream_t stream) {
             if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
             di.cus = prop.multiProcessorCount;
             if ((e = hipGetSymbolAddress(reinterpret_cast<void**>(&di.counters), HIP_SYMBOL(g_tile_counters))) != hipSuccess) return e;
-            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_eval_kernel<false>),
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_eval_kernel<false, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, MV_WAVES * kTile * kStageRow * 4)) != hipSuccess) return e;
-            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_eval_kernel<true>),
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_eval_kernel<true, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTile * kStageRow * 4)) != hipSuccess) return e;
             di.attr_set = true;
         }
@@ -555,10 +490,14 @@ hipError_t launch_field_eval(const FieldParams& p_in, hipStream_t stream) {
     const long resident = (long)di.cus * (p.V > 1 ? 1 : 8 / MV_WAVES);   // workgroups that fit at once
     const unsigned wgs = (unsigned)((MV_PERSIST && want > resident) ? resident : want);
     const size_t lds_bytes = (size_t)waves * kTile * kStageRow * 4;
-    if (p.V > 1)
-        hipLaunchKernelGGL(field_eval_kernel<true>, dim3(wgs), dim3(256), lds_bytes, stream, p);
-    else
-        hipLaunchKernelGGL(field_eval_kernel<false>, dim3(wgs), dim3(64 * MV_WAVES), lds_bytes, stream, p);
+    if (p.V > 1) {
+        if (p.stash) return hipErrorInvalidValue;                     // training stash: single-view only for now
+        hipLaunchKernelGGL((field_eval_kernel<true, false>), dim3(wgs), dim3(256), lds_bytes, stream, p);
+    } else if (p.stash) {
+        hipLaunchKernelGGL((field_eval_kernel<false, true>), dim3(wgs), dim3(64 * MV_WAVES), lds_bytes, stream, p);
+    } else {
+        hipLaunchKernelGGL((field_eval_kernel<false, false>), dim3(wgs), dim3(64 * MV_WAVES), lds_bytes, stream, p);
+    }
     return hipGetLastError();
 }
 

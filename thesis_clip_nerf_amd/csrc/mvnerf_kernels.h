@@ -22,6 +22,8 @@ struct FieldParams {
     float* embedding;      // optional (B,R,S,128): trunk output before the read-out
     float* acts_view;      // optional (4,B*V,R,S,128): layer 0 and the 3 per-view blocks (complete_output)
     float* acts_fused;     // optional (4,B,R,S,128): view mean and the 3 fusion blocks (complete_output)
+    float* stash;          // optional, V == 1 only: 13 pre-activation tensors in tile layout [slot][tile][128][32]
+    long stash_stride;     // floats per slot = n_tiles * 128 * 32
     int B, V, R, S, H, W;
     long total;            // B*R*S samples
     long n_tiles;          // ceil(total / 32)
@@ -56,5 +58,20 @@ hipError_t launch_sigma_to_alpha(const float* sigma, const float* dists, long n,
 hipError_t launch_readout(const float* emb, const float* wr, const float* br, long n, float* rgbs, hipStream_t st);
 hipError_t launch_finish_view(const float* rgb, const float* depth, long n, float* minmax, uint8_t* rgb8, uint8_t* depth8,
                               hipStream_t st);
+
+// train_ops.hip
+hipError_t launch_pack_dense(const float* src, int transpose, float* dst, hipStream_t st);
+hipError_t launch_dense_tile(const float* in_tl, const float* wstream, const float* mask_tl, const float* resid_tl,
+                             float* out_tl, long n_tiles, hipStream_t st);
+hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int g_feats, long n_tiles, float* dW, int ldn,
+                          int n_valid, float* db, int max_wgs, hipStream_t st);
+hipError_t launch_mse_grad(const float* pred, const float* label, long n, float* d_pred, float* loss, hipStream_t st);
+hipError_t launch_composite_bwd(const float* z, const float* rgbs, const float* d_rgb, const float* d_depth,
+                                const float* d_w, int n_rays, int S, float* d_rgbs, hipStream_t st);
+hipError_t launch_readout_bwd(const float* x_tl, const float* rgbs, const float* d_rgbs, const float* wr, long n_rows,
+                              long n_tiles, float* do_tl, float* g_tl, hipStream_t st);
+hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, float* db0, int max_wgs, hipStream_t st);
+hipError_t launch_adam_clip(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1, float beta2,
+                            float eps, float clip, const unsigned char* update_mask, hipStream_t st);
 
 }  // namespace mvnerf

@@ -1,0 +1,117 @@
+// MFMA building blocks shared by the fused field kernel (field_eval.hip) and the training kernels
+// (train_ops.hip): the fp32 32x32x2 MFMA wrapper, the prefetching weight stream and the 32-sample tile
+// layout ("TL") used for activations that have to live in HBM.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "mvnerf_pack.h"
+
+#ifndef MV_ABL_WLOAD
+#define MV_ABL_WLOAD 0
+#endif
+#ifndef MV_PIN_LOADS
+#define MV_PIN_LOADS 1
+#endif
+#ifndef MV_ASM_RELU
+#define MV_ASM_RELU 0
+#endif
+
+namespace mvnerf {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// relu as one v_med3_f32 (fmaxf lowers to a canonicalising v_max pair in front of every MFMA)
+__device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
+
+// relu of the 4 B operands of a step as four single v_max_f32 (fmaxf lowers to a canonicalising
+// v_max pair + s_nop in front of every MFMA).  The trailing s_nop 1 covers the VALU-write ->
+// MFMA-read wait states for the compiler-scheduled MFMAs that consume the outputs.
+__device__ __forceinline__ void relu4(const float (&in)[4], float (&b)[4]) {
+#if MV_ASM_RELU
+    asm("v_max_f32_e32 %0, 0, %4\n\tv_max_f32_e32 %1, 0, %5\n\tv_max_f32_e32 %2, 0, %6\n\tv_max_f32_e32 %3, 0, %7\n\ts_nop 1"
+        : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+        : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]));
+#else
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[e] = fmaxf(in[e], 0.0f);
+#endif
+}
+
+// The weight stream: `cur` holds the 4 chunks (4 KiB per wave) of the step being consumed, `next`
+// points at this lane's 16 bytes of the following step.  Every step first issues the loads of the
+// following step, then runs its 16 MFMAs (1024 cycles of matrix pipe), so an L2 round trip is
+// always covered, also across layer boundaries (the chunks of all layers are contiguous).
+struct WStream {
+    __amdgpu_buffer_rsrc_t rsrc;   // buffer descriptor of the packed net (SGPRs)
+    int voff;                      // lane * 16
+    int pos;                       // wave-uniform byte offset of the NEXT step (SGPR)
+    f32x4 cur[4];
+};
+
+// buffer_load_dwordx4 v, voff, rsrc, pos offen offset:imm -- the uniform stream position rides in the
+// scalar offset and the chunk index in the immediate, so a step costs no VALU address arithmetic.
+template <int kImm>
+__device__ __forceinline__ f32x4 ws_load(const WStream& ws, int pos) {
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff + kImm, pos, 0);
+    return __builtin_bit_cast(f32x4, r);
+}
+
+__device__ __forceinline__ void ws_begin(WStream& ws, const float* base, int bytes, int lane) {
+    // loads past `bytes` (the prefetch of the step after the last one) return 0 by the buffer range check
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+    ws.voff = lane * 16;
+    ws.cur[0] = ws_load<0>(ws, 0);
+    ws.cur[1] = ws_load<1024>(ws, 0);
+    ws.cur[2] = ws_load<2048>(ws, 0);
+    ws.cur[3] = ws_load<3072>(ws, 0);
+    ws.pos = 4096;
+}
+
+// One step = 4 k-steps x 4 output blocks: acc[nb] += A(cur[nb])[e] x b[e]
+__device__ __forceinline__ void mfma_step(WStream& ws, const float (&b)[4], f32x16 (&acc)[4]) {
+#if MV_ABL_WLOAD
+    const f32x4 n0 = ws.cur[1], n1 = ws.cur[2], n2 = ws.cur[3], n3 = ws.cur[0];
+#else
+    const f32x4 n0 = ws_load<0>(ws, ws.pos), n1 = ws_load<1024>(ws, ws.pos), n2 = ws_load<2048>(ws, ws.pos),
+                n3 = ws_load<3072>(ws, ws.pos);
+#endif
+#if MV_PIN_LOADS
+    __builtin_amdgcn_sched_barrier(0);      // keep the prefetch a full step ahead of its use
+#endif
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        acc[0] = mfma(ws.cur[0][e], b[e], acc[0]);
+        acc[1] = mfma(ws.cur[1][e], b[e], acc[1]);
+        acc[2] = mfma(ws.cur[2][e], b[e], acc[2]);
+        acc[3] = mfma(ws.cur[3][e], b[e], acc[3]);
+    }
+    ws.cur[0] = n0;
+    ws.cur[1] = n1;
+    ws.cur[2] = n2;
+    ws.cur[3] = n3;
+    ws.pos += 4096;
+}
+
+
+// ---- tile layout (TL): a (rows, F) activation matrix stored as [tile = row/32][feature][row%32], so that
+// "lane = sample" accesses are 128-B contiguous per feature and "lane = feature" accesses read 4 samples as
+// one float4.  Accumulator register r of block nb on lane (j, h) is feature 32*nb + acc_row(r, h) of sample j.
+__device__ __forceinline__ long tl_index(long tile, int n_feat, int feat, int j) {
+    return (tile * n_feat + feat) * 32 + j;
+}
+
+__device__ __forceinline__ void store_tl(float* __restrict__ base, long tile, int j, int h, const f32x16 (&x)[4]) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) base[tl_index(tile, 128, 32 * nb + acc_row(r, h), j)] = x[nb][r];
+}
+
+}  // namespace mvnerf

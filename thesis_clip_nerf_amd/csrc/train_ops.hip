@@ -1,0 +1,444 @@
+// Backward pass of the render path (MVVNeRFRenderer.train_step, model_v0.py:186-197) for gfx950.
+//
+// Layer-major: the forward pass (field_eval_kernel<.., kStash=true>) leaves the 13 pre-activation tensors
+// of the trunk in HBM in tile layout (mvnerf_mfma.h); each Dense layer's backward is then two MFMA kernels
+// over all 32-sample tiles:
+//   dense_tile_kernel : dX = (M^T-stream . G) (.) [pre > 0] (+ residual)    -- same weight-stream machinery
+//                       as the forward trunk, fed with the transposed kernels (pack_dense_kernel)
+//   dw_tile_kernel    : dW += relu(pre) . G^T, db += sum G                   -- samples are the MFMA K dim;
+//                       a workgroup keeps a 128x128 partial in registers over its tiles, one atomic pass at
+//                       the end (fp32 atomics, 64 KB per workgroup per layer)
+// plus small per-ray / elementwise kernels (loss gradient, compositing backward, read-out backward, layer-0
+// weight gradient with recomputed inputs, Adam with clip-by-value).
+// Gradient scope of this version: all MLP variables, with the fine-pass sample depths treated as constants
+// (no gradient through sample_pdf / sort / sample positions; see DESIGN.md "Backward").
+#include <hip/hip_runtime.h>
+
+#include "mvnerf_kernels.h"
+#include "mvnerf_math.h"
+#include "mvnerf_mfma.h"
+
+namespace mvnerf {
+
+// ---- weight images for the backward GEMMs -------------------------------------------------------------
+// src: one Keras Dense kernel [128][128] (in, out).  dst: 16384 floats in hidden-layer stream order
+// (mvnerf_pack.h) of M = src (transpose = 0) or M = src^T (transpose = 1), M indexed [k_in][n_out].
+__global__ void pack_dense_kernel(const float* __restrict__ src, int transpose, float* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kHiddenWFloats) return;
+    const int e = idx % 4, lane = (idx % kChunkFloats) / 4, i = lane & 31, h = lane >> 5;
+    const int grp = idx / kGroupFloats, nb = (idx % kGroupFloats) / kChunkFloats;
+    const int k = 32 * (grp / 4) + 8 * (grp % 4) + 4 * h + e, n = 32 * nb + i;
+    dst[idx] = transpose ? src[n * kHidden + k] : src[k * kHidden + n];
+}
+
+hipError_t launch_pack_dense(const float* src, int transpose, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(pack_dense_kernel, dim3(kHiddenWFloats / 256), dim3(256), 0, st, src, transpose, dst);
+    return hipGetLastError();
+}
+
+// ---- out = (stream . in) (.) [mask > 0] + resid, all in tile layout, 128 features, one wave per tile ----
+__global__ __launch_bounds__(256, 2) void dense_tile_kernel(const float* __restrict__ in_tl, const float* __restrict__ wstream,
+                                                            const float* __restrict__ mask_tl,
+                                                            const float* __restrict__ resid_tl, float* __restrict__ out_tl,
+                                                            long n_tiles) {
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    f32x16 bin[4], acc[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            bin[kb][r] = in_tl[tl_index(tile, 128, 32 * kb + acc_row(r, h), j)];
+            acc[kb][r] = 0.0f;
+        }
+    WStream ws;
+    ws_begin(ws, wstream, kHiddenWFloats * 4, lane);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float b[4] = {bin[kb][4 * t], bin[kb][4 * t + 1], bin[kb][4 * t + 2], bin[kb][4 * t + 3]};
+            mfma_step(ws, b, acc);
+        }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long o = tl_index(tile, 128, 32 * nb + acc_row(r, h), j);
+            float v = acc[nb][r];
+            if (mask_tl) v = mask_tl[o] > 0.0f ? v : 0.0f;
+            if (resid_tl) v = v + resid_tl[o];
+            out_tl[o] = v;
+        }
+}
+
+hipError_t launch_dense_tile(const float* in_tl, const float* wstream, const float* mask_tl, const float* resid_tl,
+                             float* out_tl, long n_tiles, hipStream_t st) {
+    hipLaunchKernelGGL(dense_tile_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, in_tl, wstream, mask_tl,
+                       resid_tl, out_tl, n_tiles);
+    return hipGetLastError();
+}
+
+// ---- dW[k][n] += sum_rows relu(a)[k] g[n] ; db[n] += sum_rows g[n] -----------------------------------------
+// a_tl: (rows,128) pre-activations in TL (relu applied on load when relu_a); g_tl: (rows, 32*kNB) in TL.
+// Wave w of a workgroup owns rows k in [32w, 32w+32) of dW and all kNB column blocks.
+template <int kNB>
+__global__ __launch_bounds__(256) void dw_tile_kernel(const float* __restrict__ a_tl, int relu_a, const float* __restrict__ g_tl,
+                                                      long n_tiles, float* __restrict__ dW, int ldn, int n_valid,
+                                                      float* __restrict__ db) {
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    f32x16 acc[kNB];
+    float dbacc[kNB];
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) {
+        dbacc[nb] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+    }
+    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        f32x4 a4[4];
+        const f32x4* ap = reinterpret_cast<const f32x4*>(a_tl + tl_index(tile, 128, 32 * w + i, 4 * h));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a4[t] = ap[2 * t];                                      // samples 8t+4h .. 8t+4h+3
+            if (relu_a) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a4[t][e] = fmaxf(a4[t][e], 0.0f);
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < kNB; ++nb) {
+            const f32x4* gp = reinterpret_cast<const f32x4*>(g_tl + tl_index(tile, 32 * kNB, 32 * nb + i, 4 * h));
+            float s = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 g4 = gp[2 * t];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[nb] = mfma(a4[t][e], g4[e], acc[nb]);
+                    s = s + g4[e];
+                }
+            }
+            dbacc[nb] = dbacc[nb] + s;
+        }
+    }
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) {
+        if (32 * nb + col < n_valid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                atomicAdd(dW + (long)(32 * w + acc_row(r, hh)) * ldn + 32 * nb + col, acc[nb][r]);
+        }
+        if (db && w == 0) {
+            const float s = dbacc[nb] + __shfl_xor(dbacc[nb], 32);
+            if (hh == 0 && 32 * nb + col < n_valid) atomicAdd(db + 32 * nb + col, s);
+        }
+    }
+}
+
+hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int g_feats, long n_tiles, float* dW, int ldn,
+                          int n_valid, float* db, int max_wgs, hipStream_t st) {
+    const unsigned wgs = (unsigned)(n_tiles < max_wgs ? n_tiles : max_wgs);
+    if (g_feats == 128)
+        hipLaunchKernelGGL(dw_tile_kernel<4>, dim3(wgs), dim3(256), 0, st, a_tl, relu_a, g_tl, n_tiles, dW, ldn, n_valid, db);
+    else if (g_feats == 32)
+        hipLaunchKernelGGL(dw_tile_kernel<1>, dim3(wgs), dim3(256), 0, st, a_tl, relu_a, g_tl, n_tiles, dW, ldn, n_valid, db);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---- loss: d pred = 2 (pred - y) / n ; loss += sum (pred - y)^2 / n   (Keras MeanSquaredError) ----
+__global__ void mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ label, long n, float inv_n,
+                                float* __restrict__ d_pred, float* __restrict__ loss) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float sq = 0.0f;
+    if (i < n) {
+        const float d = pred[i] - label[i];
+        d_pred[i] = 2.0f * d * inv_n;
+        sq = d * d * inv_n;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq = sq + __shfl_xor(sq, off);
+    if ((threadIdx.x & 63) == 0 && sq != 0.0f) atomicAdd(loss, sq);
+}
+
+hipError_t launch_mse_grad(const float* pred, const float* label, long n, float* d_pred, float* loss, hipStream_t st) {
+    hipLaunchKernelGGL(mse_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pred, label, n, 1.0f / (float)n,
+                       d_pred, loss);
+    return hipGetLastError();
+}
+
+// ---- volumetric_render backward (model_v0.py:89-100) w.r.t. the per-sample (r,g,b,sigma) -----------------
+// q_i = dL/dw_i = gR.c_i + gD z_i + gW_i ;  dL/dalpha_i = q_i T_i - (sum_{k>i} q_k w_k) / t_i ;
+// dL/dsigma_i = dL/dalpha_i * delta_i (1 - alpha_i) [sigma_i > 0] ;  dL/dc_i = w_i gR.   (depths constant)
+template <int P>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ z, const float* __restrict__ rgbs,
+                                                            const float* __restrict__ d_rgb, const float* __restrict__ d_depth,
+                                                            const float* __restrict__ d_w, int n_rays,
+                                                            float* __restrict__ d_rgbs) {
+    constexpr int S = 64 * P;
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float* zr = z + (long)ray * S;
+    const f32x4* cr = reinterpret_cast<const f32x4*>(rgbs) + (long)ray * S;
+    float zl[P + 1];
+    f32x4 c[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        zl[q] = zr[lane * P + q];
+        c[q] = cr[lane * P + q];
+    }
+    zl[P] = __shfl_down(zl[0], 1);
+    float dist[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) dist[q] = zl[q + 1] - zl[q];
+    if (P == 1) {
+        const float prev = __shfl_up(dist[0], 1);
+        if (lane == 63) dist[0] = prev;
+    } else {
+        if (lane == 63) dist[P - 1] = dist[P - 2];
+    }
+    float alpha[P], t[P], T[P], wgt[P];
+    float prod = 1.0f;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        alpha[q] = sigma_to_alpha(c[q][3], dist[q]);
+        t[q] = (1.0f - alpha[q]) + 1e-10f;
+        prod = prod * t[q];
+    }
+    float incl = prod;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float up = __shfl_up(incl, off);
+        if (lane >= off) incl = incl * up;
+    }
+    float trans = __shfl_up(incl, 1);
+    if (lane == 0) trans = 1.0f;
+    const float gr = d_rgb[3 * ray], gg = d_rgb[3 * ray + 1], gb = d_rgb[3 * ray + 2];
+    const float gd = d_depth ? d_depth[ray] : 0.0f;
+    float qw[P], qv[P];
+    float lane_sum = 0.0f;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        T[q] = trans;
+        wgt[q] = alpha[q] * trans;
+        trans = trans * t[q];
+        float qi = gr * c[q][0] + gg * c[q][1] + gb * c[q][2] + gd * zl[q];
+        if (d_w) qi = qi + d_w[(long)ray * S + lane * P + q];
+        qv[q] = qi;
+        qw[q] = qi * wgt[q];
+        lane_sum = lane_sum + qw[q];
+    }
+    float incl_s = lane_sum;                          // inclusive suffix sum over lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float dn = __shfl_down(incl_s, off);
+        if (lane + off < 64) incl_s = incl_s + dn;
+    }
+    float suffix = incl_s - lane_sum;                 // sum over later lanes
+#pragma unroll
+    for (int q = P - 1; q >= 0; --q) {
+        const float dalpha = qv[q] * T[q] - suffix / t[q];
+        const float dsigma = c[q][3] > 0.0f ? dalpha * dist[q] * (1.0f - alpha[q]) : 0.0f;
+        f32x4 o = {wgt[q] * gr, wgt[q] * gg, wgt[q] * gb, dsigma};
+        reinterpret_cast<f32x4*>(d_rgbs)[(long)ray * S + lane * P + q] = o;
+        suffix = suffix + qw[q];
+    }
+}
+
+hipError_t launch_composite_bwd(const float* z, const float* rgbs, const float* d_rgb, const float* d_depth,
+                                const float* d_w, int n_rays, int S, float* d_rgbs, hipStream_t st) {
+    const dim3 grid((n_rays + 3) / 4), block(256);
+    switch (S / 64) {
+        case 1: hipLaunchKernelGGL(composite_bwd_kernel<1>, grid, block, 0, st, z, rgbs, d_rgb, d_depth, d_w, n_rays, d_rgbs); break;
+        case 2: hipLaunchKernelGGL(composite_bwd_kernel<2>, grid, block, 0, st, z, rgbs, d_rgb, d_depth, d_w, n_rays, d_rgbs); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---- RenderReadout backward (layers.py:392-397) -----------------------------------------------------------
+// rgbs, d_rgbs: (rows,4) row-major.  x_tl: pre-activation input of the read-out (TL, 128).
+// Writes do_tl (TL, 32 features, rows 4..31 must be pre-zeroed) = dL/d(pre-activation outputs) and
+// g_tl (TL, 128) = dL/dx = (Wr . do) (.) [x > 0].
+__global__ __launch_bounds__(256) void readout_bwd_kernel(const float* __restrict__ x_tl, const float* __restrict__ rgbs,
+                                                          const float* __restrict__ d_rgbs, const float* __restrict__ wr,
+                                                          long n_rows, long n_tiles, float* __restrict__ do_tl,
+                                                          float* __restrict__ g_tl) {
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const long row = tile * 32 + j;
+    float dov[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (row < n_rows) {
+        const f32x4 y = reinterpret_cast<const f32x4*>(rgbs)[row], dy = reinterpret_cast<const f32x4*>(d_rgbs)[row];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dov[c] = dy[c] * y[c] * (1.0f - y[c]);         // sigmoid'
+        dov[3] = dy[3] * (1.0f - expf(-y[3]));                                       // softplus' = sigmoid(o) = 1 - e^-softplus
+    }
+    if (h == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) do_tl[tl_index(tile, 32, c, j)] = dov[c];
+    }
+    for (int f = 64 * h; f < 64 * h + 64; ++f) {
+        const long o = tl_index(tile, 128, f, j);
+        const f32x4 w4 = reinterpret_cast<const f32x4*>(wr)[f];
+        float g = w4[0] * dov[0];
+        g = fmaf(w4[1], dov[1], g);
+        g = fmaf(w4[2], dov[2], g);
+        g = fmaf(w4[3], dov[3], g);
+        g_tl[o] = x_tl[o] > 0.0f ? g : 0.0f;
+    }
+}
+
+hipError_t launch_readout_bwd(const float* x_tl, const float* rgbs, const float* d_rgbs, const float* wr, long n_rows,
+                              long n_tiles, float* do_tl, float* g_tl, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(do_tl, 0, (size_t)n_tiles * 32 * 32 * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(readout_bwd_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, x_tl, rgbs, d_rgbs, wr,
+                       n_rows, n_tiles, do_tl, g_tl);
+    return hipGetLastError();
+}
+
+// ---- layer-0 weight gradient: dW0[k][n] += sum_rows X0[k] g0[n], db0 += sum g0 (single view) -----------------
+// X0 = [PE(cam xyz) 60 | PE(cam dir) 60 | 2 rgb - 1 (3) | features 256] is recomputed per tile in "lane =
+// input row" form (a lane owns one Keras row k and evaluates it for the 16 samples of its half), which is the
+// MFMA A-operand layout; the feature rows are coalesced 128-B gathers of 32 consecutive channels per tap.
+struct SampleGeom {       // per sample, in wave-private LDS
+    float cam[3], dir[3], ax, ay;
+    int tl;
+};
+
+__global__ __launch_bounds__(256) void dw0_kernel(FieldParams p, const float* __restrict__ g0_tl, float* __restrict__ dW0,
+                                                  float* __restrict__ db0) {
+    __shared__ SampleGeom geom[4][32];
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kb = blockIdx.y * 4 + w;                     // 12 row blocks of 32 (384 >= 379)
+    const int krow = 32 * kb + i;
+    f32x16 acc[4];
+    float dbacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+    SampleGeom* gm = geom[w];
+    for (long tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (h == 0) {                                      // geometry of sample j = i of this tile
+            long g = tile * 32 + i;
+            if (g >= p.total) g = p.total - 1;
+            const int ray = (int)(g / p.S), b = ray / p.R;
+            const float* E = p.einv + 16 * b;              // V == 1
+            const float zz = p.z[g];
+            const float dx = p.rays_d[3 * ray], dy = p.rays_d[3 * ray + 1], dz = p.rays_d[3 * ray + 2];
+            const float wx = p.rays_o[3 * ray] + zz * dx, wy = p.rays_o[3 * ray + 1] + zz * dy, wz = p.rays_o[3 * ray + 2] + zz * dz;
+            float cam[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cam[r] = row_dot4(E, r, wx, wy, wz, 1.0f);
+            float px, py;
+            pixel_from_cam(p.k4 + 16 * b, cam, &px, &py);
+            const Taps tp = bilinear_taps(px, py, p.H, p.W);
+            SampleGeom sg;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                sg.cam[r] = cam[r];
+                sg.dir[r] = row_dot4(E, r, dx, dy, dz, 1.0f);
+            }
+            sg.ax = tp.ax;
+            sg.ay = tp.ay;
+            sg.tl = (b * p.H + tp.y0) * p.W + tp.x0;
+            gm[i] = sg;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f32x4 a4[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const SampleGeom sg = gm[8 * t + 4 * h + e];
+                float v = 0.0f;
+                if (krow < 120) {                          // positional encodings, layout (d, k, {sin,cos})
+                    const int m = krow < 60 ? krow : krow - 60;
+                    const float x = krow < 60 ? sg.cam[m / 20] : sg.dir[m / 20];
+                    float sv, cv;
+                    sincos_f32(x * (3.14159274101257324f * (float)(1 << ((m % 20) >> 1))), &sv, &cv);
+                    v = (m & 1) ? cv : sv;
+                } else if (krow < 123) {
+                    const float* im = p.images + 3 * (long)sg.tl + (krow - 120);
+                    v = bilerp(im[0] * 2.0f - 1.0f, im[3] * 2.0f - 1.0f, im[3 * p.W] * 2.0f - 1.0f,
+                               im[3 * p.W + 3] * 2.0f - 1.0f, sg.ax, sg.ay);
+                } else if (krow < 379) {
+                    const float* f = p.features + 256 * (long)sg.tl + (krow - 123);
+                    v = bilerp(f[0], f[256], f[256 * (long)p.W], f[256 * (long)p.W + 256], sg.ax, sg.ay);
+                }
+                a4[t][e] = v;
+            }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const f32x4* gp = reinterpret_cast<const f32x4*>(g0_tl + tl_index(tile, 128, 32 * nb + i, 4 * h));
+            float s = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 g4 = gp[2 * t];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[nb] = mfma(a4[t][e], g4[e], acc[nb]);
+                    s = s + g4[e];
+                }
+            }
+            dbacc[nb] = dbacc[nb] + s;
+        }
+    }
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = 32 * kb + acc_row(r, hh);
+            if (k < kIn) atomicAdd(dW0 + (long)k * kHidden + 32 * nb + col, acc[nb][r]);
+        }
+        if (kb == 0) {
+            const float s = dbacc[nb] + __shfl_xor(dbacc[nb], 32);
+            if (hh == 0) atomicAdd(db0 + 32 * nb + col, s);
+        }
+    }
+}
+
+hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, float* db0, int max_wgs, hipStream_t st) {
+    if (p.V != 1) return hipErrorInvalidValue;
+    const unsigned wgs = (unsigned)(p.n_tiles < max_wgs ? p.n_tiles : max_wgs);
+    hipLaunchKernelGGL(dw0_kernel, dim3(wgs, 3), dim3(256), 0, st, p, g0_tl, dW0, db0);
+    return hipGetLastError();
+}
+
+// ---- optimize(): clip-by-value then Adam (nerf_utils.py:8-12; tf.keras Adam, epsilon 1e-7) ----
+__global__ void adam_clip_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m,
+                                 float* __restrict__ v, long n, float lr_t, float beta1, float beta2, float eps, float clip,
+                                 const unsigned char* __restrict__ update_mask) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (update_mask && !update_mask[i]) return;
+    float g = grad[i];
+    if (clip > 0.0f) g = fminf(fmaxf(g, -clip), clip);
+    const float mi = beta1 * m[i] + (1.0f - beta1) * g;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    param[i] = param[i] - lr_t * mi / (sqrtf(vi) + eps);
+}
+
+hipError_t launch_adam_clip(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1, float beta2,
+                            float eps, float clip, const unsigned char* update_mask, hipStream_t st) {
+    hipLaunchKernelGGL(adam_clip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, param, grad, m, v, n, lr_t, beta1,
+                       beta2, eps, clip, update_mask);
+    return hipGetLastError();
+}
+
+}  // namespace mvnerf

@@ -60,6 +60,7 @@ class MVVNeRFRenderer:
         self.coarse_net = torch.from_numpy(glorot_net(rng)).to(self.device)      # Keras glorot_uniform, zero bias
         self.fine_net = torch.from_numpy(glorot_net(rng)).to(self.device)
         self._packed = None
+        self._packed_bwd = None
         self._workspace = None
 
     # ---- weights -------------------------------------------------------------------------
@@ -72,10 +73,12 @@ class MVVNeRFRenderer:
                     raise ValueError(f'{name}: {val.numel()} parameters, expected {NET_PARAMS}')
                 setattr(self, name, val)
         self._packed = None
+        self._packed_bwd = None
 
     def weights_changed(self):
         """Call after updating coarse_net / fine_net in place (e.g. an optimizer step)."""
         self._packed = None
+        self._packed_bwd = None
 
     def packed(self):
         if self._packed is None:
@@ -133,6 +136,88 @@ class MVVNeRFRenderer:
         """model_v0.py:89-100 -> (rgb, depth, weights)."""
         rgbs = torch.cat([chromacity, density[..., None]], dim=-1).contiguous()
         return ops.composite(zs.contiguous(), rgbs, return_weights=True)
+
+    # ---- training (model_v0.py:186-197, train_nerf.py:20-34, nerf_utils.py:8-12) -----------------------------
+    def compile(self, learning_rate=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7, gradients_clip=1.0,
+                train_readout=False, grad_sync=None):
+        """train_nerf.py:20-34: MSE loss, Adam(1e-4) on the coarse and fine embeddings.
+        `learning_rate` may be a callable of the step (e.g. nerf_utils.WarmupScheduler).
+        train_readout=False mirrors the reference's MultiOptimizer list, which names only the two embeddings
+        (SURVEY.md Q9); set True to update the RenderReadout kernels as well.
+        grad_sync: optional callable on the single flat gradient buffer (494 600 fp32), e.g.
+        distributed.allreduce_mean_ for data-parallel training (one collective per step)."""
+        self._opt = dict(lr=learning_rate, b1=beta_1, b2=beta_2, eps=epsilon, clip=gradients_clip, step=0)
+        self._grad = torch.zeros(2 * NET_PARAMS, dtype=torch.float32, device=self.device)
+        self._adam_m = torch.zeros_like(self._grad)
+        self._adam_v = torch.zeros_like(self._grad)
+        mask = torch.ones(NET_PARAMS, dtype=torch.uint8, device=self.device)
+        if not train_readout:
+            mask[_EMB_PARAMS:] = 0
+        self._update_mask = torch.cat([mask, mask]).contiguous()
+        self._grad_sync = grad_sync
+        self._train_bufs = {}
+
+    def loss_and_grads(self, inputs, labels, combined_features, u_coarse=None, u_fine=None, generator=None):
+        """Forward + backward of loss = MSE(labels, rgb) + MSE(labels, fine_rgb) (model_v0.py:190-194).
+        Returns (loss 1-element device tensor, flat gradient (2 x 247300): [coarse | fine], outputs 4-tuple).
+        Gradient scope: all MLP variables, fine-pass depths held constant (Backward); V = 1."""
+        if not hasattr(self, '_grad'):
+            self.compile()
+        rays_o, rays_d, images, k4, einv = [self._dev(t) for t in inputs]
+        feats = self._dev(combined_features)
+        y = self._dev(labels)
+        b, r, _ = rays_o.shape
+        u_coarse, u_fine = self._uniforms(b, r, u_coarse, u_fine, generator)
+        pc, pf = self.packed()
+        tb = self._train_bufs
+        if tb.get('key') != (b, r):
+            tb.clear()
+            tb['key'] = (b, r)
+        if self._packed_bwd is None:
+            self._packed_bwd = (ops.pack_bwd_streams(self.coarse_net), ops.pack_bwd_streams(self.fine_net))
+        geo = (images, feats, k4, einv)
+        # forward, keeping the trunk pre-activations
+        z = ops.stratified_depths(self._dev(u_coarse), self.near, self.far)
+        rgbs_c, tb['stash_c'] = ops.field_eval_stash(rays_o, rays_d, z, *geo, pc, tb.get('stash_c'))
+        rgb, depth, w = ops.composite(z, rgbs_c)
+        z_all = ops.resample(z, w, self._dev(u_fine), self.q7_mode)
+        rgbs_f, tb['stash_f'] = ops.field_eval_stash(rays_o, rays_d, z_all, *geo, pf, tb.get('stash_f'))
+        fine_rgb, fine_depth, _ = ops.composite(z_all, rgbs_f, return_weights=False)
+        # loss and its gradient w.r.t. the two rendered images
+        loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        d_rgb = ops.mse_grad(rgb, y, loss)
+        d_fine = ops.mse_grad(fine_rgb, y, loss)
+        # backward
+        self._grad.zero_()
+        gc, gf = self._grad[:NET_PARAMS], self._grad[NET_PARAMS:]
+        d_rgbs_f = ops.composite_bwd(z_all, rgbs_f, d_fine)
+        tb['scratch'] = ops.field_backward(rays_o, rays_d, z_all, *geo, self.fine_net, self._packed_bwd[1], tb['stash_f'],
+                                           rgbs_f, d_rgbs_f, gf, tb.get('scratch'))
+        d_rgbs_c = ops.composite_bwd(z, rgbs_c, d_rgb)
+        tb['scratch'] = ops.field_backward(rays_o, rays_d, z, *geo, self.coarse_net, self._packed_bwd[0], tb['stash_c'],
+                                           rgbs_c, d_rgbs_c, gc, tb['scratch'])
+        return loss, self._grad, (rgb, depth, fine_rgb, fine_depth)
+
+    def train_step(self, data, combined_features=None, u_coarse=None, u_fine=None, generator=None):
+        """model_v0.py:186-197: one optimisation step on (inputs, labels); returns {'loss': 1-element tensor}."""
+        inputs, labels = data
+        if combined_features is None:
+            bsz, v = inputs[2].shape[:2]
+            feats = self.encode(self._dev(inputs[2]).reshape(bsz * v, *inputs[2].shape[2:]))
+            combined_features = feats.reshape(bsz, v, *feats.shape[1:])
+        loss, grad, _ = self.loss_and_grads(inputs, labels, combined_features, u_coarse, u_fine, generator)
+        if self._grad_sync is not None:
+            self._grad_sync(grad)                         # one flat collective for both MLPs
+        o = self._opt
+        o['step'] += 1
+        lr = o['lr'](o['step']) if callable(o['lr']) else o['lr']
+        lr_t = lr * np.sqrt(1.0 - o['b2'] ** o['step']) / (1.0 - o['b1'] ** o['step'])
+        for k, net in enumerate((self.coarse_net, self.fine_net)):
+            sl = slice(k * NET_PARAMS, (k + 1) * NET_PARAMS)
+            ops.adam_clip(net, grad[sl], self._adam_m[sl], self._adam_v[sl], lr_t, o['b1'], o['b2'], o['eps'], o['clip'],
+                          self._update_mask[sl])
+        self.weights_changed()
+        return {'loss': loss}
 
     # ---- checkpoint (model_v0.py:199-240; per-sub-model files, load() -> False if any is missing) ----
     def _split(self, flat):

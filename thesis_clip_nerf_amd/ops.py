@@ -339,3 +339,107 @@ def finish_view(rgb, depth):
         rc = _lib.lib().mvnerf_finish_view(_p(rgb), _p(depth), n, _p(scratch), _p(rgb8), _p(depth8), _stream(rgb))
     _lib.check(rc, 'finish_view')
     return rgb8, depth8
+
+
+# ---- training step (model_v0.py:186-197): forward with stash, loss gradient, backward, Adam ---------------
+def stash_bytes(b, r, s):
+    return int(_lib.lib().mvnerf_stash_bytes(int(b), int(r), int(s)))
+
+
+def field_eval_stash(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, stash=None):
+    """Training-mode field pass (V = 1): -> (rgbs (B,R,S,4), stash uint8 tensor with the trunk pre-activations)."""
+    _chk(rays_o, 'rays_o', shape=(None, None, 3))
+    b, r, _ = rays_o.shape
+    _chk(rays_d, 'rays_d', shape=(b, r, 3))
+    _chk(z, 'z', shape=(b, r, None))
+    s = z.shape[2]
+    _chk(images, 'images', shape=(b, None, None, None, 3))
+    _, v, h, w, _ = images.shape
+    _chk(features, 'features', shape=(b, v, h, w, 256))
+    _chk(intrinsics, 'intrinsics', shape=(b, v, 4, 4))
+    _chk(extrinsics_inv, 'extrinsics_inv', shape=(b, v, 4, 4))
+    _chk(packed_net, 'packed_net', shape=(packed_net_floats(),))
+    dev = rays_o.device
+    need = stash_bytes(b, r, s)
+    if stash is None or stash.numel() < need:
+        stash = torch.empty(need, dtype=torch.uint8, device=dev)
+    rgbs = torch.empty((b, r, s, 4), dtype=torch.float32, device=dev)
+    ws = torch.empty(int(_lib.lib().mvnerf_field_workspace_bytes(b, v, r)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().mvnerf_field_eval_stash(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(intrinsics),
+                                                _p(extrinsics_inv), _p(packed_net), b, v, r, s, h, w, _p(rgbs), _p(stash),
+                                                _p(ws), _stream(rays_o))
+    _lib.check(rc, 'field_eval_stash')
+    return rgbs, stash
+
+
+def pack_bwd_streams(net_keras):
+    _chk(net_keras, 'net_keras', shape=(NET_PARAMS,))
+    out = torch.empty(12 * 16384, dtype=torch.float32, device=net_keras.device)
+    with torch.cuda.device(net_keras.device):
+        _lib.check(_lib.lib().mvnerf_pack_bwd_streams(_p(net_keras), _p(out), _stream(net_keras)), 'pack_bwd_streams')
+    return out
+
+
+def mse_grad(pred, label, loss):
+    """d pred of Keras MeanSquaredError; adds the loss value into the 1-element device tensor `loss`."""
+    _chk(pred, 'pred')
+    _chk(label, 'label', shape=tuple(pred.shape))
+    _chk(loss, 'loss', shape=(1,))
+    d = torch.empty_like(pred)
+    with torch.cuda.device(pred.device):
+        _lib.check(_lib.lib().mvnerf_mse_grad(_p(pred), _p(label), pred.numel(), _p(d), _p(loss), _stream(pred)), 'mse_grad')
+    return d
+
+
+def composite_bwd(z, rgbs, d_rgb, d_depth=None, d_weights=None):
+    """volumetric_render backward w.r.t. the per-sample (r,g,b,sigma): -> d_rgbs (...,S,4)."""
+    _chk(z, 'z')
+    s = z.shape[-1]
+    lead = tuple(z.shape[:-1])
+    _chk(rgbs, 'rgbs', shape=tuple(z.shape) + (4,))
+    _chk(d_rgb, 'd_rgb', shape=lead + (3,))
+    if d_depth is not None:
+        _chk(d_depth, 'd_depth', shape=lead)
+    if d_weights is not None:
+        _chk(d_weights, 'd_weights', shape=tuple(z.shape))
+    out = torch.empty_like(rgbs)
+    with torch.cuda.device(z.device):
+        rc = _lib.lib().mvnerf_composite_bwd(_p(z), _p(rgbs), _p(d_rgb), _p(d_depth), _p(d_weights), z.numel() // s, s,
+                                             _p(out), _stream(z))
+    _lib.check(rc, 'composite_bwd')
+    return out
+
+
+def field_backward(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, net_keras, bwd_streams, stash, rgbs,
+                   d_rgbs, grad, scratch=None):
+    """Accumulate dL/d(net variables) of one field_eval_stash call into `grad` (247300 floats, Keras order)."""
+    b, r, s = z.shape
+    _, v, h, w, _ = images.shape
+    _chk(net_keras, 'net_keras', shape=(NET_PARAMS,))
+    _chk(bwd_streams, 'bwd_streams', shape=(12 * 16384,))
+    _chk(rgbs, 'rgbs', shape=(b, r, s, 4))
+    _chk(d_rgbs, 'd_rgbs', shape=(b, r, s, 4))
+    _chk(grad, 'grad', shape=(NET_PARAMS,))
+    need = int(_lib.lib().mvnerf_field_backward_scratch_bytes(b, r, s))
+    if scratch is None or scratch.numel() < need:
+        scratch = torch.empty(need, dtype=torch.uint8, device=z.device)
+    with torch.cuda.device(z.device):
+        rc = _lib.lib().mvnerf_field_backward(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(intrinsics),
+                                              _p(extrinsics_inv), _p(net_keras), _p(bwd_streams), _p(stash), _p(rgbs),
+                                              _p(d_rgbs), b, v, r, s, h, w, _p(scratch), _p(grad), _stream(z))
+    _lib.check(rc, 'field_backward')
+    return scratch
+
+
+def adam_clip(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, clip=1.0, update_mask=None):
+    """optimize() (nerf_utils.py:8-12): clip-by-value then Adam, in place on `param`, `m`, `v`."""
+    _chk(param, 'param')
+    for t, n in ((grad, 'grad'), (m, 'm'), (v, 'v')):
+        _chk(t, n, shape=tuple(param.shape))
+    if update_mask is not None:
+        _chk(update_mask, 'update_mask', dtype=torch.uint8, shape=tuple(param.shape))
+    with torch.cuda.device(param.device):
+        rc = _lib.lib().mvnerf_adam_clip(_p(param), _p(grad), _p(m), _p(v), param.numel(), float(lr_t), float(beta1),
+                                         float(beta2), float(eps), float(clip), _p(update_mask), _stream(param))
+    _lib.check(rc, 'adam_clip')
