@@ -104,9 +104,11 @@ int mvnerf_composite(const float* z, const float* rgbs, int n_rays, int S, float
 /* Hierarchical resampling (model_v0.py:150-156): z_mid, probs = w[1:-1], sample_pdf
  * (nerf_utils.py:143-176) with explicit uniforms u_fine, concat, ascending sort.
  * z, weights, u_fine: (n_rays,64).  z_all: (n_rays,128).  Optional outputs (may be NULL):
- * z_fine (n_rays,64) fp32, above / below (n_rays,64) int32 (the integer contract of a13). */
+ * z_fine (n_rays,64) fp32, above / below (n_rays,64) int32 (the integer contract of a13),
+ * fine_rank (n_rays,64) int32: position of importance sample i inside z_all (the sort permutation, kept for
+ * the backward pass). */
 int mvnerf_resample(const float* z, const float* weights, const float* u_fine, int n_rays, int S,
-                    int q7_mode, float* z_all, float* z_fine, int32_t* above, int32_t* below,
+                    int q7_mode, float* z_all, float* z_fine, int32_t* above, int32_t* below, int32_t* fine_rank,
                     mvnerf_stream_t stream);
 
 /* ---- op-level (unfused) entry points: one per reference function, same scalar code as the fused
@@ -178,9 +180,15 @@ int mvnerf_pack_bwd_streams(const float* net_keras, float* bwd_streams, mvnerf_s
 int mvnerf_mse_grad(const float* pred, const float* label, long n, float* d_pred, float* loss, mvnerf_stream_t stream);
 
 /* volumetric_render backward (model_v0.py:89-100): d_rgb (n_rays,3), d_depth (optional, n_rays), d_weights
- * (optional, n_rays x S) -> d_rgbs (n_rays,S,4) = gradient w.r.t. the per-sample (r,g,b,sigma).  S in {64,128}. */
+ * (optional, n_rays x S) -> d_rgbs (n_rays,S,4) = gradient w.r.t. the per-sample (r,g,b,sigma), and d_z
+ * (optional, n_rays x S) = gradient w.r.t. the depths through the intervals and the depth output.  S in {64,128}. */
 int mvnerf_composite_bwd(const float* z, const float* rgbs, const float* d_rgb, const float* d_depth,
-                         const float* d_weights, int n_rays, int S, float* d_rgbs, mvnerf_stream_t stream);
+                         const float* d_weights, int n_rays, int S, float* d_rgbs, float* d_z, mvnerf_stream_t stream);
+
+/* Backward of mvnerf_resample w.r.t. the coarse weights: d_z_all (n_rays,128), fine_rank from the forward call
+ * -> d_weights (n_rays,64).  (The coarse depths depend on no variable, so no d_z is returned.) */
+int mvnerf_resample_bwd(const float* z, const float* weights, const float* u_fine, const int32_t* fine_rank,
+                        const float* d_z_all, int n_rays, int S, int q7_mode, float* d_weights, mvnerf_stream_t stream);
 
 /* Backward of one mvnerf_field_eval_stash call: accumulates dL/d(net variables) into `grad` (247300 floats, Keras
  * order, caller zeroes it) given d_rgbs (B,R,S,4).  Inputs as in the forward call, plus net_keras, the

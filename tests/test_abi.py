@@ -37,7 +37,7 @@ def test_argument_validation_without_gpu():
     assert b'null' in lib.mvnerf_last_error()
     one = ctypes.c_void_p(16)
     assert lib.mvnerf_composite(one, one, 4, 100, one, one, None, None) == -2          # S=100 unsupported
-    assert lib.mvnerf_resample(one, one, one, 4, 32, 0, one, None, None, None, None) == -2
+    assert lib.mvnerf_resample(one, one, one, 4, 32, 0, one, None, None, None, None, None) == -2
     fe_tail = [one, None, None, None, None, None, one, None]   # rgbs, tap_idx, pix, embedding, acts x2, workspace, stream
     assert lib.mvnerf_field_eval(one, one, one, one, ctypes.c_void_p(20), one, one, one, 1, 1, 4, 64, 8, 8, *fe_tail) == -3  # misaligned features
     assert lib.mvnerf_field_eval(one, one, one, one, one, one, one, one, 1, 1, 4, 64, 1, 8, *fe_tail) == -2              # H < 2

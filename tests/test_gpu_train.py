@@ -27,13 +27,38 @@ def test_composite_bwd_matches_autograd():
         g_rgb = rng.standard_normal((1, 7, 3)).astype(np.float32)
         g_depth = rng.standard_normal((1, 7)).astype(np.float32)
         g_w = rng.standard_normal((1, 7, s)).astype(np.float32)
-        tz = torch.tensor(z, dtype=torch.float64)
+        tz = torch.tensor(z, dtype=torch.float64, requires_grad=True)
         tr = torch.tensor(rgbs, dtype=torch.float64, requires_grad=True)
         rgb, depth, w = T.volumetric_render(tz, tr[..., 3], tr[..., :3])
         (rgb * torch.tensor(g_rgb) + 0).sum().add((depth * torch.tensor(g_depth)).sum()).add((w * torch.tensor(g_w)).sum()).backward()
-        got = ops.composite_bwd(dev(z), dev(rgbs), dev(g_rgb), dev(g_depth), dev(g_w)).cpu().numpy()
+        got, got_dz = ops.composite_bwd(dev(z), dev(rgbs), dev(g_rgb), dev(g_depth), dev(g_w), return_dz=True)
         ref = tr.grad.numpy()
-        assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+        assert np.abs(got.cpu().numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+        ref_dz = tz.grad.numpy()
+        assert np.abs(got_dz.cpu().numpy() - ref_dz).max() < 1e-4 * max(1.0, np.abs(ref_dz).max())
+
+
+def test_resample_bwd_matches_autograd():
+    rng = np.random.default_rng(5)
+    n = 37
+    u = rng.random((1, n, 64)).astype(np.float32)
+    _, z = O.sample_along_ray(np.zeros((1, n, 3), np.float32), np.ones((1, n, 3), np.float32), 0.3, 1.3, 64, u)
+    w = (rng.random((1, n, 64)) ** 3).astype(np.float32)
+    w[0, 0] = 0.0                                                  # uniform pdf through the +1e-5
+    uf = rng.random((1, n, 64)).astype(np.float32)
+    uf[0, :, 0] = 0.0                                              # (the discontinuous Q7 edge is left out: fp32 vs fp64 bins)
+    g_all = rng.standard_normal((1, n, 128)).astype(np.float32)
+    for q7 in (O.Q7_ZERO, O.Q7_CLAMP):
+        tw = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+        tz = torch.tensor(z, dtype=torch.float64)
+        zf = T.sample_pdf(0.5 * (tz[..., 1:] + tz[..., :-1]), tw[..., 1:-1], torch.tensor(uf, dtype=torch.float64), q7_zero=(q7 == O.Q7_ZERO))
+        z_all = torch.sort(torch.cat([tz, zf], -1), -1).values
+        (z_all * torch.tensor(g_all, dtype=torch.float64)).sum().backward()
+        z_all_k, rank = ops.resample(dev(z), dev(w), dev(uf), q7, return_rank=True)
+        assert np.abs(z_all_k.cpu().numpy() - z_all.detach().numpy()).max() < 1e-5
+        got = ops.resample_bwd(dev(z), dev(w), dev(uf), rank, dev(g_all), q7).cpu().numpy()
+        ref = tw.grad.numpy()
+        assert np.abs(got - ref).max() < 2e-3 * np.abs(ref).max() + 1e-6, (q7, np.abs(got - ref).max(), np.abs(ref).max())
 
 
 def test_adam_clip_matches_keras_formula():

@@ -120,12 +120,13 @@ int mvnerf_composite(const float* z, const float* rgbs, int n_rays, int S, float
 }
 
 int mvnerf_resample(const float* z, const float* weights, const float* u_fine, int n_rays, int S, int q7_mode,
-                    float* z_all, float* z_fine, int32_t* above, int32_t* below, mvnerf_stream_t stream) {
+                    float* z_all, float* z_fine, int32_t* above, int32_t* below, int32_t* fine_rank,
+                    mvnerf_stream_t stream) {
     if (!z || !weights || !u_fine || !z_all) return fail(MVNERF_E_ARG, "mvnerf_resample: null pointer");
     if (n_rays <= 0) return fail(MVNERF_E_ARG, "mvnerf_resample: n_rays=%d", n_rays);
     if (S != 64) return fail(MVNERF_E_SHAPE, "mvnerf_resample: S=%d, only the reference's n_samples=64 is built", S);
     if (q7_mode != MVNERF_Q7_ZERO && q7_mode != MVNERF_Q7_CLAMP) return fail(MVNERF_E_ARG, "mvnerf_resample: q7_mode=%d", q7_mode);
-    return hip_status(mvnerf::launch_resample(z, weights, u_fine, n_rays, q7_mode, z_all, z_fine, above, below,
+    return hip_status(mvnerf::launch_resample(z, weights, u_fine, n_rays, q7_mode, z_all, z_fine, above, below, fine_rank,
                                               static_cast<hipStream_t>(stream)),
                       "mvnerf_resample");
 }
@@ -266,14 +267,24 @@ int mvnerf_mse_grad(const float* pred, const float* label, long n, float* d_pred
 }
 
 int mvnerf_composite_bwd(const float* z, const float* rgbs, const float* d_rgb, const float* d_depth,
-                         const float* d_weights, int n_rays, int S, float* d_rgbs, mvnerf_stream_t stream) {
+                         const float* d_weights, int n_rays, int S, float* d_rgbs, float* d_z, mvnerf_stream_t stream) {
     if (!z || !rgbs || !d_rgb || !d_rgbs) return fail(MVNERF_E_ARG, "mvnerf_composite_bwd: null pointer");
     if (n_rays <= 0) return fail(MVNERF_E_ARG, "mvnerf_composite_bwd: n_rays=%d", n_rays);
     if (S != 64 && S != 128) return fail(MVNERF_E_SHAPE, "mvnerf_composite_bwd: S=%d, supported: 64, 128", S);
     if (!aligned16(rgbs) || !aligned16(d_rgbs)) return fail(MVNERF_E_ALIGN, "mvnerf_composite_bwd: rgbs, d_rgbs must be 16-byte aligned");
-    return hip_status(mvnerf::launch_composite_bwd(z, rgbs, d_rgb, d_depth, d_weights, n_rays, S, d_rgbs,
+    return hip_status(mvnerf::launch_composite_bwd(z, rgbs, d_rgb, d_depth, d_weights, n_rays, S, d_rgbs, d_z,
                                                    static_cast<hipStream_t>(stream)),
                       "mvnerf_composite_bwd");
+}
+
+int mvnerf_resample_bwd(const float* z, const float* weights, const float* u_fine, const int32_t* fine_rank,
+                        const float* d_z_all, int n_rays, int S, int q7_mode, float* d_weights, mvnerf_stream_t stream) {
+    if (!z || !weights || !u_fine || !fine_rank || !d_z_all || !d_weights) return fail(MVNERF_E_ARG, "mvnerf_resample_bwd: null pointer");
+    if (n_rays <= 0) return fail(MVNERF_E_ARG, "mvnerf_resample_bwd: n_rays=%d", n_rays);
+    if (S != 64) return fail(MVNERF_E_SHAPE, "mvnerf_resample_bwd: S=%d, only the reference's n_samples=64 is built", S);
+    return hip_status(mvnerf::launch_resample_bwd(z, weights, u_fine, fine_rank, d_z_all, n_rays, q7_mode, d_weights,
+                                                  static_cast<hipStream_t>(stream)),
+                      "mvnerf_resample_bwd");
 }
 
 int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float* z, const float* images,
@@ -364,7 +375,7 @@ int mvnerf_render_fwd(const float* rays_o, const float* rays_d, const float* ima
                                 R, S, H, W, w.rgbs_c, nullptr, nullptr, nullptr, nullptr, nullptr, w.dir_bias, stream)))
         return rc;
     if ((rc = mvnerf_composite(w.z, w.rgbs_c, (int)n_rays, S, rgb, depth, w.weights, stream))) return rc;
-    if ((rc = mvnerf_resample(w.z, w.weights, u_fine, (int)n_rays, S, q7_mode, w.z_all, nullptr, nullptr, nullptr, stream)))
+    if ((rc = mvnerf_resample(w.z, w.weights, u_fine, (int)n_rays, S, q7_mode, w.z_all, nullptr, nullptr, nullptr, nullptr, stream)))
         return rc;
     if ((rc = mvnerf_field_eval(rays_o, rays_d, w.z_all, images, features, intrinsics, extrinsics_inv, packed_fine, B,
                                 V, R, 2 * S, H, W, w.rgbs_f, nullptr, nullptr, nullptr, nullptr, nullptr, w.dir_bias, stream)))

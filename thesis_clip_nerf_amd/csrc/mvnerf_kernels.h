@@ -41,7 +41,7 @@ hipError_t launch_stratified(const float* u, long n, int n_samples, double near_
 hipError_t launch_composite(const float* z, const float* rgbs, int n_rays, int S, float* rgb, float* depth,
                             float* weights, hipStream_t stream);
 hipError_t launch_resample(const float* z, const float* weights, const float* u_fine, int n_rays, int q7_mode,
-                           float* z_all, float* z_fine, int32_t* above, int32_t* below, hipStream_t stream);
+                           float* z_all, float* z_fine, int32_t* above, int32_t* below, int32_t* fine_rank, hipStream_t stream);
 
 hipError_t launch_sample_pdf(const float* bins, const float* weights, const float* u, int n_rays, int q7_mode,
                              float* samples, int32_t* above, int32_t* below, hipStream_t stream);
@@ -67,7 +67,9 @@ hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int 
                           int n_valid, float* db, int max_wgs, hipStream_t st);
 hipError_t launch_mse_grad(const float* pred, const float* label, long n, float* d_pred, float* loss, hipStream_t st);
 hipError_t launch_composite_bwd(const float* z, const float* rgbs, const float* d_rgb, const float* d_depth,
-                                const float* d_w, int n_rays, int S, float* d_rgbs, hipStream_t st);
+                                const float* d_w, int n_rays, int S, float* d_rgbs, float* d_z, hipStream_t st);
+hipError_t launch_resample_bwd(const float* z, const float* weights, const float* u_fine, const int32_t* fine_rank,
+                               const float* d_z_all, int n_rays, int q7_mode, float* d_weights, hipStream_t st);
 hipError_t launch_readout_bwd(const float* x_tl, const float* rgbs, const float* d_rgbs, const float* wr, long n_rows,
                               long n_tiles, float* do_tl, float* g_tl, hipStream_t st);
 hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, float* db0, int max_wgs, hipStream_t st);

@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
                                                        const float* __restrict__ u_fine, int n_rays, int q7_mode,
                                                        float* __restrict__ z_all, float* __restrict__ z_fine,
                                                        int32_t* __restrict__ above_out,
-                                                       int32_t* __restrict__ below_out) {
+                                                       int32_t* __restrict__ below_out,
+                                                       int32_t* __restrict__ rank_out) {
     constexpr int S = 64, NB = 63, NW = 62;
     __shared__ float lds[kRaysPerWG][7 * 64];
     const int lane = threadIdx.x & 63;
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     }
     sorted[r0] = zi;
     sorted[r1] = zf;
+    if (rank_out) rank_out[base + lane] = r1;            // position of importance sample `lane` inside all_zs
     lds_fence();
     z_all[(long)ray * 128 + lane] = sorted[lane];
     z_all[(long)ray * 128 + 64 + lane] = sorted[64 + lane];
@@ -286,9 +288,10 @@ hipError_t launch_sample_pdf(const float* bins, const float* weights, const floa
 }
 
 hipError_t launch_resample(const float* z, const float* weights, const float* u_fine, int n_rays, int q7_mode,
-                           float* z_all, float* z_fine, int32_t* above, int32_t* below, hipStream_t stream) {
+                           float* z_all, float* z_fine, int32_t* above, int32_t* below, int32_t* fine_rank,
+                           hipStream_t stream) {
     hipLaunchKernelGGL(resample_kernel, dim3((n_rays + kRaysPerWG - 1) / kRaysPerWG), dim3(256), 0, stream, z,
-                       weights, u_fine, n_rays, q7_mode, z_all, z_fine, above, below);
+                       weights, u_fine, n_rays, q7_mode, z_all, z_fine, above, below, fine_rank);
     return hipGetLastError();
 }
 

@@ -180,7 +180,7 @@ template <int P>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ z, const float* __restrict__ rgbs,
                                                             const float* __restrict__ d_rgb, const float* __restrict__ d_depth,
                                                             const float* __restrict__ d_w, int n_rays,
-                                                            float* __restrict__ d_rgbs) {
+                                                            float* __restrict__ d_rgbs, float* __restrict__ d_z) {
     constexpr int S = 64 * P;
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -242,24 +242,137 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
         if (lane + off < 64) incl_s = incl_s + dn;
     }
     float suffix = incl_s - lane_sum;                 // sum over later lanes
+    float dd[P];                                      // dL/d delta_i
 #pragma unroll
     for (int q = P - 1; q >= 0; --q) {
         const float dalpha = qv[q] * T[q] - suffix / t[q];
-        const float dsigma = c[q][3] > 0.0f ? dalpha * dist[q] * (1.0f - alpha[q]) : 0.0f;
+        const float pos = c[q][3] > 0.0f ? (1.0f - alpha[q]) : 0.0f;
+        const float dsigma = dalpha * dist[q] * pos;
+        dd[q] = dalpha * c[q][3] * pos;
         f32x4 o = {wgt[q] * gr, wgt[q] * gg, wgt[q] * gb, dsigma};
         reinterpret_cast<f32x4*>(d_rgbs)[(long)ray * S + lane * P + q] = o;
         suffix = suffix + qw[q];
     }
+    if (d_z) {
+        // delta_i = z_{i+1} - z_i for i <= S-2 and delta_{S-1} = delta_{S-2} (Q6): fold the duplicate, then
+        // dL/dz_k = dd_{k-1} - dd_k (+ w_k gD from the depth)
+        if (P == 1) {
+            const float last = __shfl_down(dd[0], 1);
+            if (lane == 62) dd[0] = dd[0] + last;
+            if (lane == 63) dd[0] = 0.0f;
+        } else if (lane == 63) {
+            dd[P - 2] = dd[P - 2] + dd[P - 1];
+            dd[P - 1] = 0.0f;
+        }
+        float prev = __shfl_up(dd[P - 1], 1);
+        if (lane == 0) prev = 0.0f;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            d_z[(long)ray * S + lane * P + q] = (prev - dd[q]) + wgt[q] * gd;
+            prev = dd[q];
+        }
+    }
 }
 
 hipError_t launch_composite_bwd(const float* z, const float* rgbs, const float* d_rgb, const float* d_depth,
-                                const float* d_w, int n_rays, int S, float* d_rgbs, hipStream_t st) {
+                                const float* d_w, int n_rays, int S, float* d_rgbs, float* d_z, hipStream_t st) {
     const dim3 grid((n_rays + 3) / 4), block(256);
     switch (S / 64) {
-        case 1: hipLaunchKernelGGL(composite_bwd_kernel<1>, grid, block, 0, st, z, rgbs, d_rgb, d_depth, d_w, n_rays, d_rgbs); break;
-        case 2: hipLaunchKernelGGL(composite_bwd_kernel<2>, grid, block, 0, st, z, rgbs, d_rgb, d_depth, d_w, n_rays, d_rgbs); break;
+        case 1: hipLaunchKernelGGL(composite_bwd_kernel<1>, grid, block, 0, st, z, rgbs, d_rgb, d_depth, d_w, n_rays, d_rgbs, d_z); break;
+        case 2: hipLaunchKernelGGL(composite_bwd_kernel<2>, grid, block, 0, st, z, rgbs, d_rgb, d_depth, d_w, n_rays, d_rgbs, d_z); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// ---- hierarchical resampling backward (sample_pdf, nerf_utils.py:143-176; model_v0.py:150-156) ---------------
+// Given dL/d(all_zs) and the rank of every importance sample inside all_zs (from the forward sort), returns
+// dL/d(coarse weights).  The coarse depths are not functions of any variable, so d(bins) is not propagated.
+// One wavefront per ray; pdf/cdf/above/below are recomputed exactly as in the forward kernel.
+__global__ __launch_bounds__(256) void resample_bwd_kernel(const float* __restrict__ z, const float* __restrict__ weights,
+                                                           const float* __restrict__ u_fine, const int32_t* __restrict__ fine_rank,
+                                                           const float* __restrict__ d_z_all, int n_rays, int q7_mode,
+                                                           float* __restrict__ d_weights) {
+    constexpr int S = 64, NB = 63, NW = 62;
+    __shared__ float lds[4][5 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wv;
+    if (ray >= n_rays) return;
+    float* bins = lds[wv];
+    float* pdf = bins + 64;
+    float* cdf = pdf + 64;
+    float* dcdf = cdf + 64;
+    float* dpdf = dcdf + 64;
+    const long base = (long)ray * S;
+    const float zi = z[base + lane];
+    const float wi = weights[base + lane];
+    const float znext = __shfl_down(zi, 1);
+    if (lane < NB) bins[lane] = 0.5f * (znext + zi);
+    if (lane >= 1 && lane <= NW) pdf[lane - 1] = wi + 1e-5f;
+    dcdf[lane] = 0.0f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float wsum = 0.0f;
+    for (int k = 0; k < NW; ++k) wsum = wsum + pdf[k];
+    const bool unit_sum = fabsf(wsum) == 0.0f;
+    if (unit_sum) wsum = 1.0f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < NW) pdf[lane] = pdf[lane] / wsum;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float run = 0.0f, mycdf = 0.0f;
+    for (int k = 0; k < NW; ++k) {
+        run = run + pdf[k];
+        if (lane == k + 1) mycdf = run;
+    }
+    if (lane < NB) cdf[lane] = mycdf;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const float u = u_fine[base + lane];
+    int above = 0;
+    for (int jj = 0; jj < NB; ++jj) above += (u >= cdf[jj]) ? 1 : 0;
+    int below = above - 1;
+    below = below < 0 ? 0 : (below > NB - 1 ? NB - 1 : below);
+    const bool oob = above >= NB;
+    const int ia = oob ? NB - 1 : above;
+    const bool a_const = oob && q7_mode == 0;           // gathered value is the constant 0
+    const float cdf_a = a_const ? 0.0f : cdf[ia], bins_a = a_const ? 0.0f : bins[ia];
+    const float cdf_b = cdf[below], bins_b = bins[below];
+    const float den_raw = cdf_a - cdf_b;
+    const bool den_live = !(den_raw < 1e-5f);
+    const float den = den_live ? den_raw : 1.0f;
+    // forward: zf = bins_b + t (bins_a - bins_b), t = (u - cdf_b) / den
+    const float dzf = d_z_all[(long)ray * 128 + fine_rank[base + lane]];
+    const float dt = dzf * (bins_a - bins_b);
+    float dca = 0.0f, dcb = -dt / den;
+    if (den_live) {
+        const float k2 = dt * (u - cdf_b) / (den * den);
+        dca = -k2;
+        dcb = dcb + k2;
+    }
+    // scatter-add into d cdf (several samples may share a bin): serialise over lanes
+    for (int l = 0; l < 64; ++l) {
+        if (lane == l) {
+            if (!a_const) dcdf[ia] += dca;
+            dcdf[below] += dcb;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // cdf_j = sum_{k<j} pdf_k  ->  d pdf_k = sum_{j>k} d cdf_j
+    float mydp = 0.0f;
+    if (lane < NW)
+        for (int jj = lane + 1; jj < NB; ++jj) mydp = mydp + dcdf[jj];
+    // pdf_k = s_k / wsum  ->  d s_k = (d pdf_k - sum_m d pdf_m pdf_m) / wsum   (wsum constant when it was forced to 1)
+    float dot = lane < NW ? mydp * pdf[lane] : 0.0f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dot = dot + __shfl_xor(dot, off);
+    dpdf[lane] = lane < NW ? (mydp - (unit_sum ? 0.0f : dot)) / wsum : 0.0f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    d_weights[base + lane] = (lane >= 1 && lane <= NW) ? dpdf[lane - 1] : 0.0f;    // probs = weights[1:-1]
+}
+
+hipError_t launch_resample_bwd(const float* z, const float* weights, const float* u_fine, const int32_t* fine_rank,
+                               const float* d_z_all, int n_rays, int q7_mode, float* d_weights, hipStream_t st) {
+    hipLaunchKernelGGL(resample_bwd_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, st, z, weights, u_fine, fine_rank, d_z_all,
+                       n_rays, q7_mode, d_weights);
     return hipGetLastError();
 }
 

@@ -154,8 +154,8 @@ def composite(z, rgbs, return_weights=True):
     return rgb, depth, weights
 
 
-def resample(z, weights, u_fine, q7_mode=Q7_ZERO, return_aux=False):
-    """mvnerf_resample: -> z_all (...,2S) [+ z_fine, above, below]."""
+def resample(z, weights, u_fine, q7_mode=Q7_ZERO, return_aux=False, return_rank=False):
+    """mvnerf_resample: -> z_all (...,2S) [+ z_fine, above, below] [+ fine_rank]."""
     _chk(z, 'z')
     s = z.shape[-1]
     _chk(weights, 'weights', shape=tuple(z.shape))
@@ -165,11 +165,31 @@ def resample(z, weights, u_fine, q7_mode=Q7_ZERO, return_aux=False):
     z_fine = torch.empty_like(z) if return_aux else None
     above = torch.empty(z.shape, dtype=torch.int32, device=z.device) if return_aux else None
     below = torch.empty(z.shape, dtype=torch.int32, device=z.device) if return_aux else None
+    rank = torch.empty(z.shape, dtype=torch.int32, device=z.device) if return_rank else None
     with torch.cuda.device(z.device):
         rc = _lib.lib().mvnerf_resample(_p(z), _p(weights), _p(u_fine), n, s, int(q7_mode), _p(z_all), _p(z_fine),
-                                        _p(above), _p(below), _stream(z))
+                                        _p(above), _p(below), _p(rank), _stream(z))
     _lib.check(rc, 'resample')
-    return (z_all, z_fine, above, below) if return_aux else z_all
+    out = (z_all, z_fine, above, below) if return_aux else (z_all,)
+    if return_rank:
+        out += (rank,)
+    return out if len(out) > 1 else z_all
+
+
+def resample_bwd(z, weights, u_fine, fine_rank, d_z_all, q7_mode=Q7_ZERO):
+    """Backward of resample w.r.t. the coarse weights: -> d_weights (..., S)."""
+    _chk(z, 'z')
+    s = z.shape[-1]
+    _chk(weights, 'weights', shape=tuple(z.shape))
+    _chk(u_fine, 'u_fine', shape=tuple(z.shape))
+    _chk(fine_rank, 'fine_rank', dtype=torch.int32, shape=tuple(z.shape))
+    _chk(d_z_all, 'd_z_all', shape=tuple(z.shape[:-1]) + (2 * s,))
+    out = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        rc = _lib.lib().mvnerf_resample_bwd(_p(z), _p(weights), _p(u_fine), _p(fine_rank), _p(d_z_all), z.numel() // s, s,
+                                            int(q7_mode), _p(out), _stream(z))
+    _lib.check(rc, 'resample_bwd')
+    return out
 
 
 def render_workspace_bytes(b, v, r, s):
@@ -392,8 +412,8 @@ def mse_grad(pred, label, loss):
     return d
 
 
-def composite_bwd(z, rgbs, d_rgb, d_depth=None, d_weights=None):
-    """volumetric_render backward w.r.t. the per-sample (r,g,b,sigma): -> d_rgbs (...,S,4)."""
+def composite_bwd(z, rgbs, d_rgb, d_depth=None, d_weights=None, return_dz=False):
+    """volumetric_render backward w.r.t. the per-sample (r,g,b,sigma): -> d_rgbs (...,S,4) [+ d_z (...,S)]."""
     _chk(z, 'z')
     s = z.shape[-1]
     lead = tuple(z.shape[:-1])
@@ -404,11 +424,12 @@ def composite_bwd(z, rgbs, d_rgb, d_depth=None, d_weights=None):
     if d_weights is not None:
         _chk(d_weights, 'd_weights', shape=tuple(z.shape))
     out = torch.empty_like(rgbs)
+    d_z = torch.empty_like(z) if return_dz else None
     with torch.cuda.device(z.device):
         rc = _lib.lib().mvnerf_composite_bwd(_p(z), _p(rgbs), _p(d_rgb), _p(d_depth), _p(d_weights), z.numel() // s, s,
-                                             _p(out), _stream(z))
+                                             _p(out), _p(d_z), _stream(z))
     _lib.check(rc, 'composite_bwd')
-    return out
+    return (out, d_z) if return_dz else out
 
 
 def field_backward(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, net_keras, bwd_streams, stash, rgbs,
