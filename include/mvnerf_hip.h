@@ -172,8 +172,9 @@ int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const floa
                             const float* packed_net, int B, int V, int R, int S, int H, int W, float* rgbs, float* stash,
                             void* workspace, mvnerf_stream_t stream);
 
-/* The 12 hidden Dense kernels of one MLP, transposed, in weight-stream order (12 x 16384 floats), for the
- * dX GEMMs of the backward pass.  net_keras: 247300 floats (see mvnerf_pack_net). */
+/* The 12 hidden Dense kernels of one MLP and the three 128-row slabs of the layer-0 kernel, transposed, in
+ * weight-stream order (15 x 16384 floats), for the dX GEMMs of the backward pass.
+ * net_keras: 247300 floats (see mvnerf_pack_net). */
 int mvnerf_pack_bwd_streams(const float* net_keras, float* bwd_streams, mvnerf_stream_t stream);
 
 /* d pred = 2 (pred - label) / n and *loss += mean((pred - label)^2) (Keras MeanSquaredError, model_v0.py:193). */
@@ -192,12 +193,14 @@ int mvnerf_resample_bwd(const float* z, const float* weights, const float* u_fin
 
 /* Backward of one mvnerf_field_eval_stash call: accumulates dL/d(net variables) into `grad` (247300 floats, Keras
  * order, caller zeroes it) given d_rgbs (B,R,S,4).  Inputs as in the forward call, plus net_keras, the
- * transposed streams and the stash. */
+ * transposed streams and the stash.
+ * d_z (optional, may be NULL): (B,R,S), INCREMENTED by the gradient w.r.t. the sample depths through the sample
+ * positions (positional encoding of the camera point and the bilinear lerp factors). */
 int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float* z, const float* images,
                           const float* features, const float* intrinsics, const float* extrinsics_inv,
                           const float* net_keras, const float* bwd_streams, const float* stash, const float* rgbs,
                           const float* d_rgbs, int B, int V, int R, int S, int H, int W, void* scratch, float* grad,
-                          mvnerf_stream_t stream);
+                          float* d_z, mvnerf_stream_t stream);
 
 /* optimize(): clip-by-value (clip > 0) then one Adam step with the bias-corrected rate lr_t.
  * update_mask (optional): n bytes, 0 = leave the element untouched. */

@@ -1,6 +1,6 @@
-"""Training step on the GPU (model_v0.py:186-197) vs the differentiable torch oracle.
-Gradient scope under test: every MLP variable with the fine-pass depths held constant
-(`stop_fine_z=True` in the oracle) - the variant this round's backward implements."""
+"""Training step on the GPU (model_v0.py:186-197) vs the differentiable torch oracle, both with the
+reference's full gradient (no stop_gradient on the importance samples, SURVEY.md F12: stop=False) and with
+the fine-pass depths held constant (stop=True)."""
 import numpy as np
 import pytest
 import torch
@@ -82,15 +82,16 @@ def test_adam_clip_matches_keras_formula():
     assert np.array_equal(p.cpu().numpy()[::7], p0[::7])
 
 
-@pytest.mark.parametrize('batch', [1, 2])
-def test_loss_and_grads_match_torch_oracle(batch):
+@pytest.mark.parametrize('batch,stop', [(1, True), (2, True), (1, False), (2, False)])
+def test_loss_and_grads_match_torch_oracle(batch, stop):
     sc = make_scene(seed=40 + batch, batch=batch, n_views=1, height=16, width=16, n_rays=24, bias_scale=0.05)
     y = np.random.default_rng(2).random((batch, 24, 3)).astype(np.float32)
-    loss_ref, gc_ref, gf_ref, outs = T.train_loss_and_grads(sc['coarse'], sc['fine'], y, sc, dtype=torch.float64, stop_fine_z=True)
+    loss_ref, gc_ref, gf_ref, outs = T.train_loss_and_grads(sc['coarse'], sc['fine'], y, sc, dtype=torch.float64, stop_fine_z=stop)
     m = MVVNeRFRenderer(24, 24, n_views=1, batch_size=batch, near=sc['near'], far=sc['far'], device=DEV)
     m.set_weights(sc['coarse'], sc['fine'])
     inputs = tuple(sc[k] for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'])
-    loss, grad, out = m.loss_and_grads(inputs, y, sc['features'], u_coarse=dev(sc['u_coarse']), u_fine=dev(sc['u_fine']))
+    loss, grad, out = m.loss_and_grads(inputs, y, sc['features'], u_coarse=dev(sc['u_coarse']), u_fine=dev(sc['u_fine']),
+                                       stop_fine_z=stop)
     torch.cuda.synchronize()
     assert abs(float(loss) - loss_ref) < 1e-5
     for g, r in zip(out, outs):
@@ -100,11 +101,22 @@ def test_loss_and_grads_match_torch_oracle(batch):
         # fp32 kernels vs the fp64 oracle: besides rounding, a pre-activation within ~1e-6 of zero may take the other
         # relu branch, which moves individual entries by one sample's contribution; hence an L2 bar per section
         # (so a wrong small section cannot hide behind a large one) plus a loose max-abs bar.
+        # With the full gradient (stop=False) the coarse network also receives the term through the fine sample
+        # positions, whose positional-encoding derivative has a gain of pi*2^9: that term is ill-conditioned in fp32
+        # (torch's own fp32 autograd is 1.8e-2 away from its fp64 result on this scene), so its bar is looser and a
+        # second check makes sure the term is really there (much closer to the full than to the cut gradient).
+        loose = (not stop) and name == 'coarse'
         for lo, hi in ((0, 48512), (48512, 48640), (48640, 246784), (246784, 247300)):
             r, g = ref[lo:hi], got[lo:hi]
-            assert np.linalg.norm(g - r) < 2e-3 * np.linalg.norm(r) + 1e-9, (name, lo, hi, np.linalg.norm(g - r) / np.linalg.norm(r))
-            assert np.abs(g - r).max() < 1e-2 * np.abs(r).max() + 1e-9, (name, lo, hi)
-        print(name, 'rel L2 grad error', np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            rel = np.linalg.norm(g - r) / np.linalg.norm(r)
+            assert rel < (8e-2 if loose else 2e-3), (name, lo, hi, rel)
+            if not loose:
+                assert np.abs(g - r).max() < 1e-2 * np.abs(r).max() + 1e-9, (name, lo, hi)
+        print(name, 'stop' if stop else 'full', 'rel L2 grad error', np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    if not stop:
+        _, gc_cut, _, _ = T.train_loss_and_grads(sc['coarse'], sc['fine'], y, sc, dtype=torch.float64, stop_fine_z=True)
+        got = grad[:247300]
+        assert np.linalg.norm(got - gc_ref) < 0.2 * np.linalg.norm(gc_cut - gc_ref)
 
 
 def test_train_step_reduces_loss_and_respects_q9():

@@ -253,7 +253,14 @@ int mvnerf_pack_bwd_streams(const float* net_keras, float* bwd_streams, mvnerf_s
     for (int l = 0; l < 12; ++l) {
         const float* src = net_keras + mvnerf::kKerasBlocks + (l / 2) * mvnerf::kKerasBlockStride +
                            (l % 2) * (mvnerf::kHidden * mvnerf::kHidden + mvnerf::kHidden);
-        const hipError_t e = mvnerf::launch_pack_dense(src, 1, bwd_streams + (size_t)l * mvnerf::kHiddenWFloats,
+        const hipError_t e = mvnerf::launch_pack_dense(src, 1, 128, bwd_streams + (size_t)l * mvnerf::kHiddenWFloats,
+                                                       static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return hip_status(e, "mvnerf_pack_bwd_streams");
+    }
+    for (int slab = 0; slab < 3; ++slab) {            // layer-0 kernel rows [128 slab, 128 slab + 128), transposed
+        const int valid = mvnerf::kIn - 128 * slab < 128 ? mvnerf::kIn - 128 * slab : 128;
+        const hipError_t e = mvnerf::launch_pack_dense(net_keras + mvnerf::kKerasW0 + (size_t)slab * 128 * mvnerf::kHidden, 1, valid,
+                                                       bwd_streams + (size_t)(12 + slab) * mvnerf::kHiddenWFloats,
                                                        static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return hip_status(e, "mvnerf_pack_bwd_streams");
     }
@@ -291,7 +298,7 @@ int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float*
                           const float* features, const float* intrinsics, const float* extrinsics_inv,
                           const float* net_keras, const float* bwd_streams, const float* stash, const float* rgbs,
                           const float* d_rgbs, int B, int V, int R, int S, int H, int W, void* scratch, float* grad,
-                          mvnerf_stream_t stream) {
+                          float* d_z, mvnerf_stream_t stream) {
     using namespace mvnerf;
     if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !net_keras || !bwd_streams ||
         !stash || !rgbs || !d_rgbs || !scratch || !grad)
@@ -333,6 +340,7 @@ int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float*
     p.k4 = intrinsics; p.einv = extrinsics_inv;
     p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W; p.total = total; p.n_tiles = n_tiles;
     MV_TRY(launch_dw0(p, buf[g], grad + kKerasW0, grad + kKerasB0, kBwdMaxWGs, st));
+    if (d_z) MV_TRY(launch_field_dz(p, buf[g], bwd_streams + (size_t)12 * kHiddenWFloats, d_z, st));
 #undef MV_TRY
     return 0;
 }

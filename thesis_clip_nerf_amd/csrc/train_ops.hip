@@ -23,17 +23,19 @@ namespace mvnerf {
 // ---- weight images for the backward GEMMs -------------------------------------------------------------
 // src: one Keras Dense kernel [128][128] (in, out).  dst: 16384 floats in hidden-layer stream order
 // (mvnerf_pack.h) of M = src (transpose = 0) or M = src^T (transpose = 1), M indexed [k_in][n_out].
-__global__ void pack_dense_kernel(const float* __restrict__ src, int transpose, float* __restrict__ dst) {
+// valid_rows: rows of src that exist (a 128-row slab of the 379-row layer-0 kernel may be shorter); the rest is 0.
+__global__ void pack_dense_kernel(const float* __restrict__ src, int transpose, int valid_rows, float* __restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= kHiddenWFloats) return;
     const int e = idx % 4, lane = (idx % kChunkFloats) / 4, i = lane & 31, h = lane >> 5;
     const int grp = idx / kGroupFloats, nb = (idx % kGroupFloats) / kChunkFloats;
     const int k = 32 * (grp / 4) + 8 * (grp % 4) + 4 * h + e, n = 32 * nb + i;
-    dst[idx] = transpose ? src[n * kHidden + k] : src[k * kHidden + n];
+    const int row = transpose ? n : k;
+    dst[idx] = row < valid_rows ? (transpose ? src[n * kHidden + k] : src[k * kHidden + n]) : 0.0f;
 }
 
-hipError_t launch_pack_dense(const float* src, int transpose, float* dst, hipStream_t st) {
-    hipLaunchKernelGGL(pack_dense_kernel, dim3(kHiddenWFloats / 256), dim3(256), 0, st, src, transpose, dst);
+hipError_t launch_pack_dense(const float* src, int transpose, int valid_rows, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(pack_dense_kernel, dim3(kHiddenWFloats / 256), dim3(256), 0, st, src, transpose, valid_rows, dst);
     return hipGetLastError();
 }
 
@@ -528,6 +530,179 @@ hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, floa
     if (p.V != 1) return hipErrorInvalidValue;
     const unsigned wgs = (unsigned)(p.n_tiles < max_wgs ? p.n_tiles : max_wgs);
     hipLaunchKernelGGL(dw0_kernel, dim3(wgs, 3), dim3(256), 0, st, p, g0_tl, dW0, db0);
+    return hipGetLastError();
+}
+
+// ---- gradient of the field w.r.t. the sample depths (single view) ----------------------------------------------
+// dL/dz_sample += dir . E^-T ( dL/dcam ),  dL/dcam = PE-derivative part + K4^T dL/dq,  dL/dq from dL/dpix,
+// dL/dpix = sum_channels dL/dIn_c * d(interp_c)/d(ax, ay)   (tfa bilinear form, clamps as torch.clamp).
+// dL/dIn = W0 . g0 is formed per 128-row slab of W0 with the forward's weight-stream MFMA code (3 transposed
+// slabs); the PE rows are reduced in "lane = sample" form, the 256 feature rows go through a wave-private LDS
+// image [sample][channel] and are reduced in "lane = channel" form so that the four taps are coalesced reads.
+constexpr int kDfeRow = 257;       // floats per sample row of the LDS image (odd: conflict-free scatter)
+
+__global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const float* __restrict__ g0_tl,
+                                                          const float* __restrict__ w0t_streams, float* __restrict__ d_z) {
+    extern __shared__ __attribute__((aligned(16))) float lds_dz[];
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile = (long)blockIdx.x * 4 + wave;
+    if (tile >= p.n_tiles) return;
+    float* dfe = lds_dz + wave * (32 * kDfeRow + 64);     // [32][257] + dax[32] + day[32]
+    float* dax_s = dfe + 32 * kDfeRow;
+    float* day_s = dax_s + 32;
+
+    long g = tile * 32 + j;
+    const bool valid = g < p.total;
+    if (!valid) g = p.total - 1;
+    const int ray = (int)(g / p.S), b = ray / p.R;
+    const float* E = p.einv + 16 * b;
+    const float* K = p.k4 + 16 * b;
+    const float zz = p.z[g];
+    const float dx = p.rays_d[3 * ray], dy = p.rays_d[3 * ray + 1], dz = p.rays_d[3 * ray + 2];
+    const float wx = p.rays_o[3 * ray] + zz * dx, wy = p.rays_o[3 * ray + 1] + zz * dy, wz = p.rays_o[3 * ray + 2] + zz * dz;
+    float cam[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cam[r] = row_dot4(E, r, wx, wy, wz, 1.0f);
+    const float q0 = row_dot4(K, 0, cam[0], cam[1], cam[2], cam[3]);
+    const float q1 = row_dot4(K, 1, cam[0], cam[1], cam[2], cam[3]);
+    const float q2 = row_dot4(K, 2, cam[0], cam[1], cam[2], cam[3]);
+    const float den = fmaxf(q2, 1e-8f);
+    const float pxr = q0 / den, pyr = q1 / den;
+    const float px = fminf(fmaxf(pxr, -1e6f), 1e6f), py = fminf(fmaxf(pyr, -1e6f), 1e6f);
+    const Taps tp = bilinear_taps(px, py, p.H, p.W);
+    const int tl = (b * p.H + tp.y0) * p.W + tp.x0;
+    const float ux = px - fminf(fmaxf(0.0f, floorf(px)), (float)(p.W - 2));      // unclamped lerp factors
+    const float uy = py - fminf(fmaxf(0.0f, floorf(py)), (float)(p.H - 2));
+
+    f32x16 bin[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bin[kb][r] = g0_tl[tl_index(tile, 128, 32 * kb + acc_row(r, h), j)];
+
+    float dcam[3] = {0.0f, 0.0f, 0.0f};
+    float dax = 0.0f, day = 0.0f;
+#pragma unroll 1
+    for (int slab = 0; slab < 3; ++slab) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+        WStream ws;
+        ws_begin(ws, w0t_streams + (size_t)slab * kHiddenWFloats, kHiddenWFloats * 4, lane);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float bq[4] = {bin[kb][4 * t], bin[kb][4 * t + 1], bin[kb][4 * t + 2], bin[kb][4 * t + 3]};
+                mfma_step(ws, bq, acc);
+            }
+        // acc[nb][r] = dL/dIn[row = 128*slab + 32*nb + acc_row(r,h)] of sample j
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 128 * slab + 32 * nb + acc_row(r, h);
+                const float v = acc[nb][r];
+                if (slab == 0 && row < 60) {
+                    // PE(cam xyz) rows come as (sin, cos) pairs in adjacent registers; handle the pair at the sin row
+                    if ((r & 1) == 0) {
+                        const int d = row / 20, oct = (row % 20) >> 1;
+                        const float f = 3.14159274101257324f * (float)(1 << oct);
+                        float sv, cv;
+                        sincos_f32(cam[d] * f, &sv, &cv);
+                        const float contrib = f * (v * cv - acc[nb][r + 1] * sv);
+                        if (d == 0) dcam[0] += contrib;
+                        else if (d == 1) dcam[1] += contrib;
+                        else dcam[2] += contrib;
+                    }
+                } else if (row >= 120 && row < 123) {
+                    // rgb rows: taps of this lane's own sample (scalar loads)
+                    const float* im = p.images + 3 * (long)tl + (row - 120);
+                    const float a = im[0] * 2.0f - 1.0f, bq = im[3] * 2.0f - 1.0f, cq = im[3 * p.W] * 2.0f - 1.0f,
+                                dq = im[3 * p.W + 3] * 2.0f - 1.0f;
+                    dax += v * ((1.0f - tp.ay) * (bq - a) + tp.ay * (dq - cq));
+                    day += v * ((cq - a) + tp.ax * ((dq - cq) - (bq - a)));
+                } else if (row >= 123 && row < 379) {
+                    dfe[j * kDfeRow + (row - 123)] = v;
+                }
+            }
+    }
+    if (lane < 32) {
+        dax_s[lane] = 0.0f;
+        day_s[lane] = 0.0f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // feature channels, lane = channel (4 passes of 64), one sample at a time: coalesced tap reads
+#pragma unroll 1
+    for (int sidx = 0; sidx < 32; ++sidx) {
+        const int tls = __shfl(tl, sidx);
+        const float axs = __shfl(tp.ax, sidx), ays = __shfl(tp.ay, sidx);
+        const float* f = p.features + 256 * (long)tls;
+        float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int c = 64 * pass + lane;
+            const float v = dfe[sidx * kDfeRow + c];
+            const float vtl = f[c], vtr = f[256 + c], vbl = f[256 * (long)p.W + c], vbr = f[256 * (long)p.W + 256 + c];
+            pa += v * ((1.0f - ays) * (vtr - vtl) + ays * (vbr - vbl));
+            pb += v * ((vbl - vtl) + axs * ((vbr - vbl) - (vtr - vtl)));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            pa += __shfl_xor(pa, off);
+            pb += __shfl_xor(pb, off);
+        }
+        if (lane == 0) {
+            dax_s[sidx] = pa;
+            day_s[sidx] = pb;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // combine the two half-waves' PE / rgb parts, add the feature part of this lane's sample
+#pragma unroll
+    for (int d = 0; d < 3; ++d) dcam[d] += __shfl_xor(dcam[d], 32);
+    dax += __shfl_xor(dax, 32);
+    day += __shfl_xor(day, 32);
+    dax += dax_s[j];
+    day += day_s[j];
+    // clamps (torch.clamp semantics: gradient passes inside the closed range)
+    const float dpx = (ux >= 0.0f && ux <= 1.0f && pxr >= -1e6f && pxr <= 1e6f) ? dax : 0.0f;
+    const float dpy = (uy >= 0.0f && uy <= 1.0f && pyr >= -1e6f && pyr <= 1e6f) ? day : 0.0f;
+    const float dq0 = dpx / den, dq1 = dpy / den;
+    const float dq2 = q2 >= 1e-8f ? -(dpx * q0 + dpy * q1) / (den * den) : 0.0f;
+    float dc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dc[c] = K[c] * dq0 + K[4 + c] * dq1 + K[8 + c] * dq2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dc[c] += dcam[c];
+    float dzv = 0.0f;
+    const float dirv[3] = {dx, dy, dz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float dworld = E[a] * dc[0] + E[4 + a] * dc[1] + E[8 + a] * dc[2] + E[12 + a] * dc[3];
+        dzv += dworld * dirv[a];
+    }
+    if (valid && h == 0) d_z[g] += dzv;
+}
+
+hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, hipStream_t st) {
+    if (p.V != 1) return hipErrorInvalidValue;
+    const size_t lds_bytes = (size_t)4 * (32 * kDfeRow + 64) * sizeof(float);
+    static bool attr_done[16] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 16 && !attr_done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_dz_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(field_dz_kernel, dim3((unsigned)((p.n_tiles + 3) / 4)), dim3(256), lds_bytes, st, p, g0_tl, w0t_streams, d_z);
     return hipGetLastError();
 }
 

@@ -157,10 +157,13 @@ class MVVNeRFRenderer:
         self._grad_sync = grad_sync
         self._train_bufs = {}
 
-    def loss_and_grads(self, inputs, labels, combined_features, u_coarse=None, u_fine=None, generator=None):
+    def loss_and_grads(self, inputs, labels, combined_features, u_coarse=None, u_fine=None, generator=None,
+                       stop_fine_z=False):
         """Forward + backward of loss = MSE(labels, rgb) + MSE(labels, fine_rgb) (model_v0.py:190-194).
         Returns (loss 1-element device tensor, flat gradient (2 x 247300): [coarse | fine], outputs 4-tuple).
-        Gradient scope: all MLP variables, fine-pass depths held constant (Backward); V = 1."""
+        Gradient scope: all MLP variables, including the path the reference leaves open (no stop_gradient on the
+        importance samples): fine loss -> fine sample positions -> sample_pdf -> coarse weights ->
+        coarse network.  stop_fine_z=True cuts that path (cheaper).  V = 1."""
         if not hasattr(self, '_grad'):
             self.compile()
         rays_o, rays_d, images, k4, einv = [self._dev(t) for t in inputs]
@@ -180,7 +183,7 @@ class MVVNeRFRenderer:
         z = ops.stratified_depths(self._dev(u_coarse), self.near, self.far)
         rgbs_c, tb['stash_c'] = ops.field_eval_stash(rays_o, rays_d, z, *geo, pc, tb.get('stash_c'))
         rgb, depth, w = ops.composite(z, rgbs_c)
-        z_all = ops.resample(z, w, self._dev(u_fine), self.q7_mode)
+        z_all, rank = ops.resample(z, w, self._dev(u_fine), self.q7_mode, return_rank=True)
         rgbs_f, tb['stash_f'] = ops.field_eval_stash(rays_o, rays_d, z_all, *geo, pf, tb.get('stash_f'))
         fine_rgb, fine_depth, _ = ops.composite(z_all, rgbs_f, return_weights=False)
         # loss and its gradient w.r.t. the two rendered images
@@ -190,22 +193,27 @@ class MVVNeRFRenderer:
         # backward
         self._grad.zero_()
         gc, gf = self._grad[:NET_PARAMS], self._grad[NET_PARAMS:]
-        d_rgbs_f = ops.composite_bwd(z_all, rgbs_f, d_fine)
+        if stop_fine_z:
+            d_rgbs_f, d_z_all, d_w = ops.composite_bwd(z_all, rgbs_f, d_fine), None, None
+        else:
+            d_rgbs_f, d_z_all = ops.composite_bwd(z_all, rgbs_f, d_fine, return_dz=True)
         tb['scratch'] = ops.field_backward(rays_o, rays_d, z_all, *geo, self.fine_net, self._packed_bwd[1], tb['stash_f'],
-                                           rgbs_f, d_rgbs_f, gf, tb.get('scratch'))
-        d_rgbs_c = ops.composite_bwd(z, rgbs_c, d_rgb)
+                                           rgbs_f, d_rgbs_f, gf, tb.get('scratch'), d_z=d_z_all)
+        if not stop_fine_z:
+            d_w = ops.resample_bwd(z, w, self._dev(u_fine), rank, d_z_all, self.q7_mode)
+        d_rgbs_c = ops.composite_bwd(z, rgbs_c, d_rgb, d_weights=d_w)
         tb['scratch'] = ops.field_backward(rays_o, rays_d, z, *geo, self.coarse_net, self._packed_bwd[0], tb['stash_c'],
                                            rgbs_c, d_rgbs_c, gc, tb['scratch'])
         return loss, self._grad, (rgb, depth, fine_rgb, fine_depth)
 
-    def train_step(self, data, combined_features=None, u_coarse=None, u_fine=None, generator=None):
+    def train_step(self, data, combined_features=None, u_coarse=None, u_fine=None, generator=None, stop_fine_z=False):
         """model_v0.py:186-197: one optimisation step on (inputs, labels); returns {'loss': 1-element tensor}."""
         inputs, labels = data
         if combined_features is None:
             bsz, v = inputs[2].shape[:2]
             feats = self.encode(self._dev(inputs[2]).reshape(bsz * v, *inputs[2].shape[2:]))
             combined_features = feats.reshape(bsz, v, *feats.shape[1:])
-        loss, grad, _ = self.loss_and_grads(inputs, labels, combined_features, u_coarse, u_fine, generator)
+        loss, grad, _ = self.loss_and_grads(inputs, labels, combined_features, u_coarse, u_fine, generator, stop_fine_z)
         if self._grad_sync is not None:
             self._grad_sync(grad)                         # one flat collective for both MLPs
         o = self._opt

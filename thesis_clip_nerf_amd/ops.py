@@ -395,7 +395,7 @@ def field_eval_stash(rays_o, rays_d, z, images, features, intrinsics, extrinsics
 
 def pack_bwd_streams(net_keras):
     _chk(net_keras, 'net_keras', shape=(NET_PARAMS,))
-    out = torch.empty(12 * 16384, dtype=torch.float32, device=net_keras.device)
+    out = torch.empty(15 * 16384, dtype=torch.float32, device=net_keras.device)
     with torch.cuda.device(net_keras.device):
         _lib.check(_lib.lib().mvnerf_pack_bwd_streams(_p(net_keras), _p(out), _stream(net_keras)), 'pack_bwd_streams')
     return out
@@ -433,12 +433,15 @@ def composite_bwd(z, rgbs, d_rgb, d_depth=None, d_weights=None, return_dz=False)
 
 
 def field_backward(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, net_keras, bwd_streams, stash, rgbs,
-                   d_rgbs, grad, scratch=None):
-    """Accumulate dL/d(net variables) of one field_eval_stash call into `grad` (247300 floats, Keras order)."""
+                   d_rgbs, grad, scratch=None, d_z=None):
+    """Accumulate dL/d(net variables) of one field_eval_stash call into `grad` (247300 floats, Keras order);
+    d_z (optional, (B,R,S)) is incremented by the gradient through the sample positions."""
     b, r, s = z.shape
     _, v, h, w, _ = images.shape
     _chk(net_keras, 'net_keras', shape=(NET_PARAMS,))
-    _chk(bwd_streams, 'bwd_streams', shape=(12 * 16384,))
+    _chk(bwd_streams, 'bwd_streams', shape=(15 * 16384,))
+    if d_z is not None:
+        _chk(d_z, 'd_z', shape=(b, r, s))
     _chk(rgbs, 'rgbs', shape=(b, r, s, 4))
     _chk(d_rgbs, 'd_rgbs', shape=(b, r, s, 4))
     _chk(grad, 'grad', shape=(NET_PARAMS,))
@@ -448,7 +451,7 @@ def field_backward(rays_o, rays_d, z, images, features, intrinsics, extrinsics_i
     with torch.cuda.device(z.device):
         rc = _lib.lib().mvnerf_field_backward(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(intrinsics),
                                               _p(extrinsics_inv), _p(net_keras), _p(bwd_streams), _p(stash), _p(rgbs),
-                                              _p(d_rgbs), b, v, r, s, h, w, _p(scratch), _p(grad), _stream(z))
+                                              _p(d_rgbs), b, v, r, s, h, w, _p(scratch), _p(grad), _p(d_z), _stream(z))
     _lib.check(rc, 'field_backward')
     return scratch
 
