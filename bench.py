@@ -58,11 +58,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    backend = os.environ.get('MVNERF_BENCH_BACKEND', 'nccl')      # 'gloo' only to rehearse N>1 on a one-GPU box
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank if backend == 'nccl' else local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)       # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -105,7 +112,7 @@ def main():
         out = step(ev[i])
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, dev)            # the slowest rank's clock (no-op at world 1)
+    elapsed = max_over_ranks(elapsed, dev if backend == 'nccl' else 'cpu')   # the slowest rank's clock (no-op at world 1)
 
     rays_per_step = b * r * world
     ms_per_step = 1e3 * elapsed / args.steps
