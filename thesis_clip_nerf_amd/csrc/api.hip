@@ -213,14 +213,14 @@ long tiles_for(int B, int R, int S) { return ((long)B * R * S + 31) / 32; }
 constexpr int kBwdMaxWGs = 512;      // resident workgroups of the dW kernels (2 per CU)
 }  // namespace
 
-size_t mvnerf_stash_bytes(int B, int R, int S) {
-    if (B <= 0 || R <= 0 || S <= 0) return 0;
-    return (size_t)13 * tiles_for(B, R, S) * 128 * 32 * sizeof(float);
+size_t mvnerf_stash_bytes(int B, int V, int R, int S) {
+    if (B <= 0 || V <= 0 || R <= 0 || S <= 0) return 0;
+    return (size_t)(7 * V + 7) * tiles_for(B, R, S) * 128 * 32 * sizeof(float);     // 7 per-view + 7 fused slots
 }
 
-size_t mvnerf_field_backward_scratch_bytes(int B, int R, int S) {
-    if (B <= 0 || R <= 0 || S <= 0) return 0;
-    return (size_t)tiles_for(B, R, S) * (3 * 128 + 32) * 32 * sizeof(float);
+size_t mvnerf_field_backward_scratch_bytes(int B, int V, int R, int S) {
+    if (B <= 0 || V <= 0 || R <= 0 || S <= 0) return 0;
+    return (size_t)tiles_for(B, R, S) * ((size_t)3 * V * 128 + 32) * 32 * sizeof(float);
 }
 
 int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const float* z, const float* images,
@@ -229,8 +229,8 @@ int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const floa
                             void* workspace, mvnerf_stream_t stream) {
     if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !packed_net || !rgbs || !stash || !workspace)
         return fail(MVNERF_E_ARG, "mvnerf_field_eval_stash: null pointer");
-    if (V != 1) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_stash: V=%d, the training path is built for one source view", V);
-    if (B <= 0 || R <= 0 || S <= 0 || H < 2 || W < 2) return fail(MVNERF_E_ARG, "mvnerf_field_eval_stash: B=%d R=%d S=%d H=%d W=%d", B, R, S, H, W);
+    if (B <= 0 || V <= 0 || R <= 0 || S <= 0 || H < 2 || W < 2) return fail(MVNERF_E_ARG, "mvnerf_field_eval_stash: B=%d V=%d R=%d S=%d H=%d W=%d", B, V, R, S, H, W);
+    if (V > 1 && ((long)R * S) % 32 != 0) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_stash: R*S=%ld must be a multiple of 32 when V > 1", (long)R * S);
     const long total = (long)B * R * S;
     if (total >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_stash: B*R*S too large");
     if (!aligned16(features) || !aligned16(packed_net) || !aligned16(rgbs) || !aligned16(stash) || !aligned16(workspace))
@@ -243,7 +243,9 @@ int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const floa
     p.total = total;
     p.n_tiles = (total + 31) / 32;
     p.stash = stash;
-    p.stash_stride = p.n_tiles * 128 * 32;
+    p.stash_stride = (long)V * p.n_tiles * 4096;
+    p.stash_fused = stash + 7 * p.stash_stride;
+    p.stash_fused_stride = p.n_tiles * 4096;
     return hip_status(mvnerf::launch_field_eval(p, static_cast<hipStream_t>(stream)), "mvnerf_field_eval_stash");
 }
 
@@ -303,35 +305,42 @@ int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float*
     if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !net_keras || !bwd_streams ||
         !stash || !rgbs || !d_rgbs || !scratch || !grad)
         return fail(MVNERF_E_ARG, "mvnerf_field_backward: null pointer");
-    if (V != 1) return fail(MVNERF_E_SHAPE, "mvnerf_field_backward: V=%d, the training path is built for one source view", V);
-    if (B <= 0 || R <= 0 || S <= 0 || H < 2 || W < 2) return fail(MVNERF_E_ARG, "mvnerf_field_backward: bad sizes");
+    if (B <= 0 || V <= 0 || R <= 0 || S <= 0 || H < 2 || W < 2) return fail(MVNERF_E_ARG, "mvnerf_field_backward: bad sizes");
+    if (V > 1 && ((long)R * S) % 32 != 0) return fail(MVNERF_E_SHAPE, "mvnerf_field_backward: R*S must be a multiple of 32 when V > 1");
     if (!aligned16(net_keras) || !aligned16(bwd_streams) || !aligned16(stash) || !aligned16(rgbs) || !aligned16(d_rgbs) || !aligned16(scratch))
         return fail(MVNERF_E_ALIGN, "mvnerf_field_backward: net_keras, bwd_streams, stash, rgbs, d_rgbs, scratch must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const long total = (long)B * R * S, n_tiles = (total + 31) / 32;
-    const size_t slot = (size_t)n_tiles * 128 * 32;
-    float* buf[3] = {static_cast<float*>(scratch), static_cast<float*>(scratch) + slot, static_cast<float*>(scratch) + 2 * slot};
-    float* do_tl = static_cast<float*>(scratch) + 3 * slot;
-    auto stash_slot = [&](int s) { return stash + (size_t)s * slot; };
+    const long total = (long)B * R * S, n_tiles = (total + 31) / 32, view_tiles = n_tiles * V;
+    const size_t vslot = (size_t)view_tiles * 4096, fslot = (size_t)n_tiles * 4096;
+    float* buf[3] = {static_cast<float*>(scratch), static_cast<float*>(scratch) + vslot, static_cast<float*>(scratch) + 2 * vslot};
+    float* do_tl = static_cast<float*>(scratch) + 3 * vslot;
+    auto view_slot = [&](int k) { return stash + (size_t)k * vslot; };                   // x0,h1,x1,h2,x2,h3,x3
+    auto fused_slot = [&](int m) { return stash + 7 * vslot + (size_t)m * fslot; };      // mean,h4,x4,h5,x5,h6,x6
     hipError_t e;
 #define MV_TRY(call) if ((e = (call)) != hipSuccess) return hip_status(e, "mvnerf_field_backward")
     // read-out
-    MV_TRY(launch_readout_bwd(stash_slot(12), rgbs, d_rgbs, net_keras + kKerasWr, total, n_tiles, do_tl, buf[0], st));
-    MV_TRY(launch_dw_tile(stash_slot(12), 1, do_tl, 32, n_tiles, grad + kKerasWr, 4, 4, grad + kKerasBr, kBwdMaxWGs, st));
+    MV_TRY(launch_readout_bwd(fused_slot(6), rgbs, d_rgbs, net_keras + kKerasWr, total, n_tiles, do_tl, buf[0], st));
+    MV_TRY(launch_dw_tile(fused_slot(6), 1, do_tl, 32, n_tiles, grad + kKerasWr, 4, 4, grad + kKerasBr, kBwdMaxWGs, st));
     int g = 0;                                         // buf[g] holds dL/d(block output)
     for (int bi = 5; bi >= 0; --bi) {
+        if (bi == 2 && V > 1) {                        // reduce_mean over views (layers.py:368-370)
+            const int gn = (g + 1) % 3;
+            MV_TRY(launch_view_broadcast(buf[g], V, n_tiles / B, n_tiles, buf[gn], st));
+            g = gn;
+        }
+        const bool fused = bi >= 3;
+        const long nt = fused ? n_tiles : view_tiles;
+        const float* pre_in = fused ? fused_slot(2 * (bi - 3)) : view_slot(2 * bi);
+        const float* pre_hid = fused ? fused_slot(2 * (bi - 3) + 1) : view_slot(2 * bi + 1);
         float* gb = grad + kKerasBlocks + bi * kKerasBlockStride;
         const int dh = (g + 1) % 3, gn = (g + 2) % 3;
         // second Dense of the block: out = x_in + W2^T relu(hid) + b2
-        MV_TRY(launch_dw_tile(stash_slot(2 * bi + 1), 1, buf[g], 128, n_tiles, gb + kHidden * kHidden + kHidden, kHidden, kHidden,
+        MV_TRY(launch_dw_tile(pre_hid, 1, buf[g], 128, nt, gb + kHidden * kHidden + kHidden, kHidden, kHidden,
                               gb + 2 * kHidden * kHidden + kHidden, kBwdMaxWGs, st));
-        MV_TRY(launch_dense_tile(buf[g], bwd_streams + (size_t)(2 * bi + 1) * kHiddenWFloats, stash_slot(2 * bi + 1), nullptr,
-                                 buf[dh], n_tiles, st));
+        MV_TRY(launch_dense_tile(buf[g], bwd_streams + (size_t)(2 * bi + 1) * kHiddenWFloats, pre_hid, nullptr, buf[dh], nt, st));
         // first Dense: hid = W1^T relu(x_in) + b1 ; the identity branch adds dL/d(out) back
-        MV_TRY(launch_dw_tile(stash_slot(2 * bi), 1, buf[dh], 128, n_tiles, gb, kHidden, kHidden, gb + kHidden * kHidden,
-                              kBwdMaxWGs, st));
-        MV_TRY(launch_dense_tile(buf[dh], bwd_streams + (size_t)(2 * bi) * kHiddenWFloats, stash_slot(2 * bi), buf[g], buf[gn],
-                                 n_tiles, st));
+        MV_TRY(launch_dw_tile(pre_in, 1, buf[dh], 128, nt, gb, kHidden, kHidden, gb + kHidden * kHidden, kBwdMaxWGs, st));
+        MV_TRY(launch_dense_tile(buf[dh], bwd_streams + (size_t)(2 * bi) * kHiddenWFloats, pre_in, buf[g], buf[gn], nt, st));
         g = gn;
     }
     // layer 0 (inputs recomputed)

@@ -278,14 +278,16 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, (kMultiView || kS
             }
         }
 
-        if (kStash) store_tl(p.stash, tile, j, h, x);        // slot 0: layer-0 output (training mode, V = 1)
+        // training mode: view tile index (all 32 samples of a tile share b because R*S % 32 == 0 when V > 1)
+        const long vtile = kMultiView ? ((long)bv * (p.n_tiles / p.B) + (tile - (long)b * (p.n_tiles / p.B))) : tile;
+        if (kStash) store_tl(p.stash, vtile, j, h, x);       // per-view slot 0: layer-0 output
         // ---- per-view feature blocks (layers.py:365-366); optional complete_output taps (:376-377) ----
         const long vslot = (long)p.B * p.V * p.R * p.S * 128;
         if (p.acts_view && valid) store_acc(p.acts_view + 128 * vrow, h, x);
 #pragma unroll 1
         for (int bi = 0; bi < 3; ++bi) {
             resnet_block<kStash>(ws, net + kPackBHidden + 256 * bi, h, x, hid,
-                                 kStash ? p.stash + (1 + 2 * bi) * p.stash_stride : nullptr, p.stash_stride, tile, j);
+                                 kStash ? p.stash + (1 + 2 * bi) * p.stash_stride : nullptr, p.stash_stride, vtile, j);
             if (p.acts_view && valid) store_acc(p.acts_view + (bi + 1) * vslot + 128 * vrow, h, x);
         }
 
@@ -301,11 +303,13 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, (kMultiView || kS
     }
 
     // ---- fusion blocks (layers.py:373-374); the stream continues into hidden layer 6 ----
+    if (kStash) store_tl(p.stash_fused, tile, j, h, x);                           // fused slot 0: the view mean
     if (p.acts_fused && valid) store_acc(p.acts_fused + 128 * g, h, x);           // the view mean
 #pragma unroll 1
     for (int bi = 3; bi < 6; ++bi) {
         resnet_block<kStash>(ws, net + kPackBHidden + 256 * bi, h, x, hid,
-                             kStash ? p.stash + (1 + 2 * bi) * p.stash_stride : nullptr, p.stash_stride, tile, j);
+                             kStash ? p.stash_fused + (1 + 2 * (bi - 3)) * p.stash_fused_stride : nullptr,
+                             p.stash_fused_stride, tile, j);
         if (p.acts_fused && valid) store_acc(p.acts_fused + (bi - 2) * p.total * 128 + 128 * g, h, x);
     }
 
@@ -472,6 +476,10 @@ hipError_t launch_field_eval(const FieldParams& p_in, hipStream_t stream) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, MV_WAVES * kTile * kStageRow * 4)) != hipSuccess) return e;
             if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_eval_kernel<true, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTile * kStageRow * 4)) != hipSuccess) return e;
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_eval_kernel<true, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTile * kStageRow * 4)) != hipSuccess) return e;
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_eval_kernel<false, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, MV_WAVES * kTile * kStageRow * 4)) != hipSuccess) return e;
             di.attr_set = true;
         }
     }
@@ -491,8 +499,12 @@ hipError_t launch_field_eval(const FieldParams& p_in, hipStream_t stream) {
     const unsigned wgs = (unsigned)((MV_PERSIST && want > resident) ? resident : want);
     const size_t lds_bytes = (size_t)waves * kTile * kStageRow * 4;
     if (p.V > 1) {
-        if (p.stash) return hipErrorInvalidValue;                     // training stash: single-view only for now
-        hipLaunchKernelGGL((field_eval_kernel<true, false>), dim3(wgs), dim3(256), lds_bytes, stream, p);
+        if (p.stash) {
+            if (((long)p.R * p.S) % 32 != 0) return hipErrorInvalidValue;     // tiles must not straddle scenes
+            hipLaunchKernelGGL((field_eval_kernel<true, true>), dim3(wgs), dim3(256), lds_bytes, stream, p);
+        } else {
+            hipLaunchKernelGGL((field_eval_kernel<true, false>), dim3(wgs), dim3(256), lds_bytes, stream, p);
+        }
     } else if (p.stash) {
         hipLaunchKernelGGL((field_eval_kernel<false, true>), dim3(wgs), dim3(64 * MV_WAVES), lds_bytes, stream, p);
     } else {

@@ -22,8 +22,11 @@ struct FieldParams {
     float* embedding;      // optional (B,R,S,128): trunk output before the read-out
     float* acts_view;      // optional (4,B*V,R,S,128): layer 0 and the 3 per-view blocks (complete_output)
     float* acts_fused;     // optional (4,B,R,S,128): view mean and the 3 fusion blocks (complete_output)
-    float* stash;          // optional, V == 1 only: 13 pre-activation tensors in tile layout [slot][tile][128][32]
-    long stash_stride;     // floats per slot = n_tiles * 128 * 32
+    // training mode (kStash): pre-activation tensors in tile layout [slot][tile][128][32]
+    float* stash;          // 7 per-view slots (x0,h1,x1,h2,x2,h3,x3), tile = view tile (b*V+v)*tiles_per_b + k
+    long stash_stride;     // floats per per-view slot = V * n_tiles * 4096
+    float* stash_fused;    // 7 fused slots (mean,h4,x4,h5,x5,h6,x6), tile = b*tiles_per_b + k
+    long stash_fused_stride;   // floats per fused slot = n_tiles * 4096
     int B, V, R, S, H, W;
     long total;            // B*R*S samples
     long n_tiles;          // ceil(total / 32)
@@ -74,6 +77,7 @@ hipError_t launch_resample_bwd(const float* z, const float* weights, const float
 hipError_t launch_readout_bwd(const float* x_tl, const float* rgbs, const float* d_rgbs, const float* wr, long n_rows,
                               long n_tiles, float* do_tl, float* g_tl, hipStream_t st);
 hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, float* db0, int max_wgs, hipStream_t st);
+hipError_t launch_view_broadcast(const float* g_fused, int V, long tiles_per_b, long n_tiles, float* g_view, hipStream_t st);
 hipError_t launch_adam_clip(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1, float beta2,
                             float eps, float clip, const unsigned char* update_mask, hipStream_t st);
 

@@ -421,7 +421,46 @@ hipError_t launch_readout_bwd(const float* x_tl, const float* rgbs, const float*
     return hipGetLastError();
 }
 
-// ---- layer-0 weight gradient: dW0[k][n] += sum_rows X0[k] g0[n], db0 += sum g0 (single view) -----------------
+// Row r of the (B*V*R*S)-row per-view tensors -> batch-view index, global ray, global sample index.
+struct ViewRow {
+    int bv, b, ray;
+    long g;
+};
+__device__ __forceinline__ ViewRow view_row(const FieldParams& p, long row) {
+    const long rs = (long)p.R * p.S;
+    const long total_view = rs * p.B * p.V;
+    if (row >= total_view) row = total_view - 1;
+    ViewRow vr;
+    vr.bv = (int)(row / rs);
+    const long in_b = row - (long)vr.bv * rs;
+    vr.b = vr.bv / p.V;
+    vr.ray = vr.b * p.R + (int)(in_b / p.S);
+    vr.g = (long)vr.b * rs + in_b;
+    return vr;
+}
+
+// g_view[(b*V+v)*tpb + k] = g_fused[b*tpb + k] / V   (backward of reduce_mean over views, layers.py:368-370)
+__global__ void view_broadcast_kernel(const float* __restrict__ g_fused, int V, long tiles_per_b, long n_tiles,
+                                      float* __restrict__ g_view) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // over V * n_tiles * 4096 / 4 float4s
+    const long per_tile = 1024;
+    if (i >= (long)V * n_tiles * per_tile) return;
+    const long vt = i / per_tile, off = i % per_tile;
+    const long bv = vt / tiles_per_b, k = vt % tiles_per_b;
+    const f32x4 v = reinterpret_cast<const f32x4*>(g_fused)[((bv / V) * tiles_per_b + k) * per_tile + off];
+    const float inv = 1.0f / (float)V;
+    f32x4 o = {v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv};
+    reinterpret_cast<f32x4*>(g_view)[i] = o;
+}
+
+hipError_t launch_view_broadcast(const float* g_fused, int V, long tiles_per_b, long n_tiles, float* g_view, hipStream_t st) {
+    const long n = (long)V * n_tiles * 1024;
+    hipLaunchKernelGGL(view_broadcast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g_fused, V, tiles_per_b,
+                       n_tiles, g_view);
+    return hipGetLastError();
+}
+
+// ---- layer-0 weight gradient: dW0[k][n] += sum_rows X0[k] g0[n], db0 += sum g0 (all view rows) ---------------
 // X0 = [PE(cam xyz) 60 | PE(cam dir) 60 | 2 rgb - 1 (3) | features 256] is recomputed per tile in "lane =
 // input row" form (a lane owns one Keras row k and evaluates it for the 16 samples of its half), which is the
 // MFMA A-operand layout; the feature rows are coalesced 128-B gathers of 32 consecutive channels per tap.
@@ -444,14 +483,14 @@ __global__ __launch_bounds__(256) void dw0_kernel(FieldParams p, const float* __
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
     SampleGeom* gm = geom[w];
-    for (long tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    const long view_tiles = p.n_tiles * p.V;
+    for (long tile = blockIdx.x; tile < view_tiles; tile += gridDim.x) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (h == 0) {                                      // geometry of sample j = i of this tile
-            long g = tile * 32 + i;
-            if (g >= p.total) g = p.total - 1;
-            const int ray = (int)(g / p.S), b = ray / p.R;
-            const float* E = p.einv + 16 * b;              // V == 1
-            const float zz = p.z[g];
+        if (h == 0) {                                      // geometry of sample j = i of this view tile
+            const ViewRow vr = view_row(p, tile * 32 + i);
+            const int ray = vr.ray, b = vr.bv;             // `b` indexes the (B*V) cameras / grids below
+            const float* E = p.einv + 16 * b;
+            const float zz = p.z[vr.g];
             const float dx = p.rays_d[3 * ray], dy = p.rays_d[3 * ray + 1], dz = p.rays_d[3 * ray + 2];
             const float wx = p.rays_o[3 * ray] + zz * dx, wy = p.rays_o[3 * ray + 1] + zz * dy, wz = p.rays_o[3 * ray + 2] + zz * dz;
             float cam[4];
@@ -527,8 +566,8 @@ __global__ __launch_bounds__(256) void dw0_kernel(FieldParams p, const float* __
 }
 
 hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, float* db0, int max_wgs, hipStream_t st) {
-    if (p.V != 1) return hipErrorInvalidValue;
-    const unsigned wgs = (unsigned)(p.n_tiles < max_wgs ? p.n_tiles : max_wgs);
+    const long view_tiles = p.n_tiles * p.V;
+    const unsigned wgs = (unsigned)(view_tiles < max_wgs ? view_tiles : max_wgs);
     hipLaunchKernelGGL(dw0_kernel, dim3(wgs, 3), dim3(256), 0, st, p, g0_tl, dW0, db0);
     return hipGetLastError();
 }
@@ -546,16 +585,16 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
     extern __shared__ __attribute__((aligned(16))) float lds_dz[];
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long tile = (long)blockIdx.x * 4 + wave;
-    if (tile >= p.n_tiles) return;
+    const long tile = (long)blockIdx.x * 4 + wave;          // view tile
+    if (tile >= p.n_tiles * p.V) return;
     float* dfe = lds_dz + wave * (32 * kDfeRow + 64);     // [32][257] + dax[32] + day[32]
     float* dax_s = dfe + 32 * kDfeRow;
     float* day_s = dax_s + 32;
 
-    long g = tile * 32 + j;
-    const bool valid = g < p.total;
-    if (!valid) g = p.total - 1;
-    const int ray = (int)(g / p.S), b = ray / p.R;
+    const bool valid = tile * 32 + j < p.total * p.V;
+    const ViewRow vr = view_row(p, tile * 32 + j);
+    const long g = vr.g;
+    const int ray = vr.ray, b = vr.bv;                      // `b` indexes the (B*V) cameras / grids below
     const float* E = p.einv + 16 * b;
     const float* K = p.k4 + 16 * b;
     const float zz = p.z[g];
@@ -686,11 +725,10 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
         const float dworld = E[a] * dc[0] + E[4 + a] * dc[1] + E[8 + a] * dc[2] + E[12 + a] * dc[3];
         dzv += dworld * dirv[a];
     }
-    if (valid && h == 0) d_z[g] += dzv;
+    if (valid && h == 0) atomicAdd(d_z + g, dzv);           // the V views of a sample add up
 }
 
 hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, hipStream_t st) {
-    if (p.V != 1) return hipErrorInvalidValue;
     const size_t lds_bytes = (size_t)4 * (32 * kDfeRow + 64) * sizeof(float);
     static bool attr_done[16] = {};
     int dev = 0;
@@ -702,7 +740,7 @@ hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL(field_dz_kernel, dim3((unsigned)((p.n_tiles + 3) / 4)), dim3(256), lds_bytes, st, p, g0_tl, w0t_streams, d_z);
+    hipLaunchKernelGGL(field_dz_kernel, dim3((unsigned)((p.n_tiles * p.V + 3) / 4)), dim3(256), lds_bytes, st, p, g0_tl, w0t_streams, d_z);
     return hipGetLastError();
 }
 

@@ -163,7 +163,7 @@ class MVVNeRFRenderer:
         Returns (loss 1-element device tensor, flat gradient (2 x 247300): [coarse | fine], outputs 4-tuple).
         Gradient scope: all MLP variables, including the path the reference leaves open (no stop_gradient on the
         importance samples): fine loss -> fine sample positions -> sample_pdf -> coarse weights ->
-        coarse network.  stop_fine_z=True cuts that path (cheaper).  V = 1."""
+        coarse network.  stop_fine_z=True cuts that path (cheaper)."""
         if not hasattr(self, '_grad'):
             self.compile()
         rays_o, rays_d, images, k4, einv = [self._dev(t) for t in inputs]
@@ -173,9 +173,9 @@ class MVVNeRFRenderer:
         u_coarse, u_fine = self._uniforms(b, r, u_coarse, u_fine, generator)
         pc, pf = self.packed()
         tb = self._train_bufs
-        if tb.get('key') != (b, r):
+        if tb.get('key') != (b, images.shape[1], r):
             tb.clear()
-            tb['key'] = (b, r)
+            tb['key'] = (b, images.shape[1], r)
         if self._packed_bwd is None:
             self._packed_bwd = (ops.pack_bwd_streams(self.coarse_net), ops.pack_bwd_streams(self.fine_net))
         geo = (images, feats, k4, einv)

@@ -362,12 +362,12 @@ def finish_view(rgb, depth):
 
 
 # ---- training step (model_v0.py:186-197): forward with stash, loss gradient, backward, Adam ---------------
-def stash_bytes(b, r, s):
-    return int(_lib.lib().mvnerf_stash_bytes(int(b), int(r), int(s)))
+def stash_bytes(b, v, r, s):
+    return int(_lib.lib().mvnerf_stash_bytes(int(b), int(v), int(r), int(s)))
 
 
 def field_eval_stash(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, stash=None):
-    """Training-mode field pass (V = 1): -> (rgbs (B,R,S,4), stash uint8 tensor with the trunk pre-activations)."""
+    """Training-mode field pass: -> (rgbs (B,R,S,4), stash uint8 tensor with the trunk pre-activations)."""
     _chk(rays_o, 'rays_o', shape=(None, None, 3))
     b, r, _ = rays_o.shape
     _chk(rays_d, 'rays_d', shape=(b, r, 3))
@@ -380,7 +380,7 @@ def field_eval_stash(rays_o, rays_d, z, images, features, intrinsics, extrinsics
     _chk(extrinsics_inv, 'extrinsics_inv', shape=(b, v, 4, 4))
     _chk(packed_net, 'packed_net', shape=(packed_net_floats(),))
     dev = rays_o.device
-    need = stash_bytes(b, r, s)
+    need = stash_bytes(b, v, r, s)
     if stash is None or stash.numel() < need:
         stash = torch.empty(need, dtype=torch.uint8, device=dev)
     rgbs = torch.empty((b, r, s, 4), dtype=torch.float32, device=dev)
@@ -445,7 +445,7 @@ def field_backward(rays_o, rays_d, z, images, features, intrinsics, extrinsics_i
     _chk(rgbs, 'rgbs', shape=(b, r, s, 4))
     _chk(d_rgbs, 'd_rgbs', shape=(b, r, s, 4))
     _chk(grad, 'grad', shape=(NET_PARAMS,))
-    need = int(_lib.lib().mvnerf_field_backward_scratch_bytes(b, r, s))
+    need = int(_lib.lib().mvnerf_field_backward_scratch_bytes(b, v, r, s))
     if scratch is None or scratch.numel() < need:
         scratch = torch.empty(need, dtype=torch.uint8, device=z.device)
     with torch.cuda.device(z.device):
