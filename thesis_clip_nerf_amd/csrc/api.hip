@@ -211,6 +211,7 @@ int mvnerf_finish_view(const float* rgb, const float* depth, long n, float* minm
 namespace {
 long tiles_for(int B, int R, int S) { return ((long)B * R * S + 31) / 32; }
 constexpr int kBwdMaxWGs = 512;      // resident workgroups of the dW kernels (2 per CU)
+constexpr int kFusedBwdWGs = 1024;   // fused dX+dW kernel: 32 KiB LDS per workgroup, 4 per CU
 }  // namespace
 
 size_t mvnerf_stash_bytes(int B, int V, int R, int S) {
@@ -334,13 +335,12 @@ int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float*
         const float* pre_hid = fused ? fused_slot(2 * (bi - 3) + 1) : view_slot(2 * bi + 1);
         float* gb = grad + kKerasBlocks + bi * kKerasBlockStride;
         const int dh = (g + 1) % 3, gn = (g + 2) % 3;
-        // second Dense of the block: out = x_in + W2^T relu(hid) + b2
-        MV_TRY(launch_dw_tile(pre_hid, 1, buf[g], 128, nt, gb + kHidden * kHidden + kHidden, kHidden, kHidden,
-                              gb + 2 * kHidden * kHidden + kHidden, kBwdMaxWGs, st));
-        MV_TRY(launch_dense_tile(buf[g], bwd_streams + (size_t)(2 * bi + 1) * kHiddenWFloats, pre_hid, nullptr, buf[dh], nt, st));
+        // second Dense of the block: out = x_in + W2^T relu(hid) + b2      (dX and dW in one pass over the tiles)
+        MV_TRY(launch_dense_bwd_fused(buf[g], pre_hid, bwd_streams + (size_t)(2 * bi + 1) * kHiddenWFloats, nullptr, buf[dh], nt,
+                                      gb + kHidden * kHidden + kHidden, gb + 2 * kHidden * kHidden + kHidden, kFusedBwdWGs, st));
         // first Dense: hid = W1^T relu(x_in) + b1 ; the identity branch adds dL/d(out) back
-        MV_TRY(launch_dw_tile(pre_in, 1, buf[dh], 128, nt, gb, kHidden, kHidden, gb + kHidden * kHidden, kBwdMaxWGs, st));
-        MV_TRY(launch_dense_tile(buf[dh], bwd_streams + (size_t)(2 * bi) * kHiddenWFloats, pre_in, buf[g], buf[gn], nt, st));
+        MV_TRY(launch_dense_bwd_fused(buf[dh], pre_in, bwd_streams + (size_t)(2 * bi) * kHiddenWFloats, buf[g], buf[gn], nt, gb,
+                                      gb + kHidden * kHidden, kFusedBwdWGs, st));
         g = gn;
     }
     // layer 0 (inputs recomputed)

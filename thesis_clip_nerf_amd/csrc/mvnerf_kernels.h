@@ -69,6 +69,8 @@ hipError_t launch_dense_tile(const float* in_tl, const float* wstream, const flo
                              float* out_tl, long n_tiles, hipStream_t st);
 hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int g_feats, long n_tiles, float* dW, int ldn,
                           int n_valid, float* db, int max_wgs, hipStream_t st);
+hipError_t launch_dense_bwd_fused(const float* g_tl, const float* a_tl, const float* wstream, const float* resid_tl,
+                                  float* da_tl, long n_tiles, float* dW, float* db, int max_wgs, hipStream_t st);
 hipError_t launch_mse_grad(const float* pred, const float* label, long n, float* d_pred, float* loss, hipStream_t st);
 hipError_t launch_composite_bwd(const float* z, const float* rgbs, const float* d_rgb, const float* d_depth,
                                 const float* d_w, int n_rays, int S, float* d_rgbs, float* d_z, hipStream_t st);

@@ -154,6 +154,113 @@ hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int 
     return hipGetLastError();
 }
 
+// ---- fused backward of one Dense(128 -> 128): dX and dW from ONE pass over the tile ---------------------------
+//   y = W^T relu(a) + b        G = dL/dy (TL),  a = pre-activation input (TL)
+//   dL/da = (W . G) (.) [a > 0] (+ resid)      dW += relu(a) . G^T      db += sum G
+// A workgroup (4 waves) stages the G and a tiles once in LDS (coalesced 16-byte loads, XOR-swizzled so that both
+// the "lane = sample" dword reads and the "lane = feature" 16-byte reads are conflict-free or 2-way) and splits
+// the work by 32-row block: wave w produces rows [32w, 32w+32) of dL/da (64 MFMAs, its quarter of the transposed
+// weight stream) and rows [32w, 32w+32) of dW (64 MFMAs, samples as K), accumulating dW in registers over all the
+// workgroup's tiles and adding it once at the end.
+__device__ __forceinline__ int swz_f4(int f, int chunk) { return f * 8 + (chunk ^ (f & 7)); }     // float4 index
+
+__global__ __launch_bounds__(256, 2) void dense_bwd_fused_kernel(const float* __restrict__ g_tl, const float* __restrict__ a_tl,
+                                                                 const float* __restrict__ wstream,
+                                                                 const float* __restrict__ resid_tl, float* __restrict__ da_tl,
+                                                                 long n_tiles, float* __restrict__ dW, float* __restrict__ db) {
+    __shared__ __attribute__((aligned(16))) f32x4 sG[1024], sA[1024];          // 2 x 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, i = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    f32x16 dwacc[4];
+    float dbacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dwacc[nb][r] = 0.0f;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wstream), 0, kHiddenWFloats * 4, 0x00020000);
+    const int wvoff = lane * 16 + 1024 * w;               // chunk (grp, nb = w) of every 4 KiB group
+
+    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();                                   // previous tile fully consumed
+        const f32x4* gsrc = reinterpret_cast<const f32x4*>(g_tl + tile * 4096);
+        const f32x4* asrc = reinterpret_cast<const f32x4*>(a_tl + tile * 4096);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int q = tid + 256 * m;
+            const int dst = swz_f4(q >> 3, q & 7);
+            sG[dst] = gsrc[q];
+            sA[dst] = asrc[q];
+        }
+        __syncthreads();
+        // ---- dL/da rows of block w: out[32w + i'][j] = sum_n M[n][32w + i'] G[n][j] ----
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        f32x4 wcur = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, 0, 0));
+#pragma unroll
+        for (int grp = 0; grp < 16; ++grp) {
+            const f32x4 wnext = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, 4096 * (grp + 1), 0));
+            const int kb = grp >> 2, t = grp & 3;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = 32 * kb + 8 * t + 4 * h + e;                       // contraction index of this k-step
+                const float gv = reinterpret_cast<const float*>(sG)[swz_f4(n, j >> 2) * 4 + (j & 3)];
+                acc = mfma(wcur[e], gv, acc);
+            }
+            wcur = wnext;
+        }
+        // ---- dW rows of block w: dW[32w + i][n] += sum_j relu(a)[32w + i][j] G[n][j] ----
+        f32x4 a4[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a4[t] = sA[swz_f4(32 * w + i, 2 * t + h)];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a4[t][e] = fmaxf(a4[t][e], 0.0f);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            float sgsum = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 g4 = sG[swz_f4(32 * nb + i, 2 * t + h)];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dwacc[nb] = mfma(a4[t][e], g4[e], dwacc[nb]);
+                    sgsum = sgsum + g4[e];
+                }
+            }
+            dbacc[nb] = dbacc[nb] + sgsum;
+        }
+        // ---- epilogue of dL/da: relu mask from the staged a tile, optional residual, store ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * w + acc_row(r, h);
+            const float av = reinterpret_cast<const float*>(sA)[swz_f4(f, j >> 2) * 4 + (j & 3)];
+            const long o = tl_index(tile, 128, f, j);
+            float v = av > 0.0f ? acc[r] : 0.0f;
+            if (resid_tl) v = v + resid_tl[o];
+            da_tl[o] = v;
+        }
+    }
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(dW + (long)(32 * w + acc_row(r, hh)) * kHidden + 32 * nb + col, dwacc[nb][r]);
+        if (w == 0) {
+            const float sdb = dbacc[nb] + __shfl_xor(dbacc[nb], 32);
+            if (hh == 0) atomicAdd(db + 32 * nb + col, sdb);
+        }
+    }
+}
+
+hipError_t launch_dense_bwd_fused(const float* g_tl, const float* a_tl, const float* wstream, const float* resid_tl,
+                                  float* da_tl, long n_tiles, float* dW, float* db, int max_wgs, hipStream_t st) {
+    const unsigned wgs = (unsigned)(n_tiles < max_wgs ? n_tiles : max_wgs);
+    hipLaunchKernelGGL(dense_bwd_fused_kernel, dim3(wgs), dim3(256), 0, st, g_tl, a_tl, wstream, resid_tl, da_tl, n_tiles, dW, db);
+    return hipGetLastError();
+}
+
 // ---- loss: d pred = 2 (pred - y) / n ; loss += sum (pred - y)^2 / n   (Keras MeanSquaredError) ----
 __global__ void mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ label, long n, float inv_n,
                                 float* __restrict__ d_pred, float* __restrict__ loss) {
