@@ -65,8 +65,6 @@ hipError_t launch_finish_view(const float* rgb, const float* depth, long n, floa
 // train_ops.hip
 hipError_t launch_pack_dense(const float* src, int transpose, int valid_rows, float* dst, hipStream_t st);
 hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, hipStream_t st);
-hipError_t launch_dense_tile(const float* in_tl, const float* wstream, const float* mask_tl, const float* resid_tl,
-                             float* out_tl, long n_tiles, hipStream_t st);
 hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int g_feats, long n_tiles, float* dW, int ldn,
                           int n_valid, float* db, int max_wgs, hipStream_t st);
 hipError_t launch_dense_bwd_fused(const float* g_tl, const float* a_tl, const float* wstream, const float* resid_tl,

@@ -26,9 +26,6 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// relu as one v_med3_f32 (fmaxf lowers to a canonicalising v_max pair in front of every MFMA)
-__device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
-
 // relu of the 4 B operands of a step as four single v_max_f32 (fmaxf lowers to a canonicalising
 // v_max pair + s_nop in front of every MFMA).  The trailing s_nop 1 covers the VALU-write ->
 // MFMA-read wait states for the compiler-scheduled MFMAs that consume the outputs.

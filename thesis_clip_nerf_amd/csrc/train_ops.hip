@@ -3,15 +3,14 @@
 // Layer-major: the forward pass (field_eval_kernel<.., kStash=true>) leaves the 13 pre-activation tensors
 // of the trunk in HBM in tile layout (mvnerf_mfma.h); each Dense layer's backward is then two MFMA kernels
 // over all 32-sample tiles:
-//   dense_tile_kernel : dX = (M^T-stream . G) (.) [pre > 0] (+ residual)    -- same weight-stream machinery
-//                       as the forward trunk, fed with the transposed kernels (pack_dense_kernel)
-//   dw_tile_kernel    : dW += relu(pre) . G^T, db += sum G                   -- samples are the MFMA K dim;
-//                       a workgroup keeps a 128x128 partial in registers over its tiles, one atomic pass at
-//                       the end (fp32 atomics, 64 KB per workgroup per layer)
-// plus small per-ray / elementwise kernels (loss gradient, compositing backward, read-out backward, layer-0
-// weight gradient with recomputed inputs, Adam with clip-by-value).
-// Gradient scope of this version: all MLP variables, with the fine-pass sample depths treated as constants
-// (no gradient through sample_pdf / sort / sample positions; see DESIGN.md "Backward").
+// over all 32-sample tiles, fused in dense_bwd_fused_kernel:
+//   dX = (W . G) (.) [pre > 0] (+ residual)   -- the forward's weight-stream MFMA code fed with transposed kernels
+//   dW += relu(pre) . G^T, db += sum G        -- samples are the MFMA K dimension; a workgroup keeps its
+//                                                128x128 partial in registers over its tiles and adds it once
+//                                                with fp32 atomics
+// plus per-ray / elementwise kernels: loss gradient, compositing backward (incl. depths), resample backward
+// (sample_pdf + un-sort), read-out backward, layer-0 weight gradient with recomputed inputs, the gradient w.r.t.
+// the sample positions, Adam with clip-by-value.  See DESIGN.md section 8.
 #include <hip/hip_runtime.h>
 
 #include "mvnerf_kernels.h"
@@ -36,50 +35,6 @@ __global__ void pack_dense_kernel(const float* __restrict__ src, int transpose, 
 
 hipError_t launch_pack_dense(const float* src, int transpose, int valid_rows, float* dst, hipStream_t st) {
     hipLaunchKernelGGL(pack_dense_kernel, dim3(kHiddenWFloats / 256), dim3(256), 0, st, src, transpose, valid_rows, dst);
-    return hipGetLastError();
-}
-
-// ---- out = (stream . in) (.) [mask > 0] + resid, all in tile layout, 128 features, one wave per tile ----
-__global__ __launch_bounds__(256, 2) void dense_tile_kernel(const float* __restrict__ in_tl, const float* __restrict__ wstream,
-                                                            const float* __restrict__ mask_tl,
-                                                            const float* __restrict__ resid_tl, float* __restrict__ out_tl,
-                                                            long n_tiles) {
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= n_tiles) return;
-    f32x16 bin[4], acc[4];
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            bin[kb][r] = in_tl[tl_index(tile, 128, 32 * kb + acc_row(r, h), j)];
-            acc[kb][r] = 0.0f;
-        }
-    WStream ws;
-    ws_begin(ws, wstream, kHiddenWFloats * 4, lane);
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float b[4] = {bin[kb][4 * t], bin[kb][4 * t + 1], bin[kb][4 * t + 2], bin[kb][4 * t + 3]};
-            mfma_step(ws, b, acc);
-        }
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long o = tl_index(tile, 128, 32 * nb + acc_row(r, h), j);
-            float v = acc[nb][r];
-            if (mask_tl) v = mask_tl[o] > 0.0f ? v : 0.0f;
-            if (resid_tl) v = v + resid_tl[o];
-            out_tl[o] = v;
-        }
-}
-
-hipError_t launch_dense_tile(const float* in_tl, const float* wstream, const float* mask_tl, const float* resid_tl,
-                             float* out_tl, long n_tiles, hipStream_t st) {
-    hipLaunchKernelGGL(dense_tile_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, in_tl, wstream, mask_tl,
-                       resid_tl, out_tl, n_tiles);
     return hipGetLastError();
 }
 
