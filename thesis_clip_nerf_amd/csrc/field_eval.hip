@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, (kMultiView || kS
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o = mfma(ws.cur[t][e], relu(x[kb][4 * t + e]), o);
+            for (int e = 0; e < 4; ++e) o = mfma(ws.cur[t][e], fmaxf(x[kb][4 * t + e], 0.0f), o);
         }
         if (kb < 3) {
 #pragma unroll
