@@ -139,7 +139,7 @@ def main():
             # the fine-pass launch is the dominant kernel instance (2/3 of the FLOPs)
             achieved = flops_f / (fine_ms * 1e-3) / 1e12
             result['roofline'] = {
-                'bound': 'mfma', 'kernel': 'field_eval_kernel<false> (fine pass, S=128)' if args.views == 1 else 'field_eval_kernel<true> (fine pass, S=128)',
+                'bound': 'mfma', 'kernel': 'field_eval_kernel<false,false> (fine pass, S=128)' if args.views == 1 else 'field_eval_kernel<true,false> (fine pass, S=128)',
                 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                 'traffic': None, 'flop_per_launch': flops_f, 'avg_launch_ms': fine_ms,
                 'coarse_launch': {'flop_per_launch': flops_c, 'avg_launch_ms': coarse_ms,
