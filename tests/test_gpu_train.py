@@ -133,3 +133,33 @@ def test_train_step_reduces_loss_and_respects_q9():
     assert losses[-1] < losses[0], losses
     assert torch.equal(m.coarse_net[-516:], readout_before)           # RenderReadout is not in the optimizer list (Q9)
     assert not torch.equal(m.coarse_net[:100], dev(sc['coarse'])[:100])
+
+
+def test_train_nerf_loop_checkpoint_and_resume(tmp_path):
+    """The train_nerf.py-shaped loop (train_nerf.py:37-65): fits, validation dumps, training_progress.json,
+    per-sub-model checkpoints, and resuming from the recorded epoch."""
+    import json
+    from thesis_clip_nerf_amd import train_nerf as TN
+    np.random.seed(0)
+    train = TN.SyntheticSceneDataset(n_scenes=2, n_perspectives=4, height=16, width=16, seed=0)
+    valid = TN.SyntheticSceneDataset(n_scenes=1, n_perspectives=4, height=16, width=16, seed=1)
+    valid_data = {'src_colors': [valid.colors[0][0]], 'src_camera_configs': [valid.cameras[0][0]],
+                  'tgt_camera_config': valid.cameras[0][1], 'tgt_colors': valid.colors[0][1],
+                  'combined_features': torch.from_numpy(np.array([[valid.features[0][0]]], dtype=np.float32))}
+    gen = TN.MVNeRFDataGenerator(train, n_rays_train=32, batch_size=1, n_views=1)
+    (inputs, feats), targets = gen[0]
+    assert inputs[0].shape == (1, 32, 3) and inputs[2].shape == (1, 1, 16, 16, 3) and feats.shape == (1, 1, 16, 16, 256)
+    assert targets.shape == (1, 32, 3) and len(gen) == 2
+    model = MVVNeRFRenderer(32, 512, n_views=1, batch_size=1, near=0.3, far=1.3, device=DEV)
+    TN.compile_model(model)
+    ckpt = str(tmp_path / 'model_final')
+    logs = []
+    hist = TN.train_model(model, gen, 2, 1, str(tmp_path), ckpt, valid_data, log=logs.append)
+    assert len(hist) == 2 and all(np.isfinite(hist)) and len(logs) == 2
+    assert json.load(open(tmp_path / 'training_progress.json')) == {'epoch': 2}
+    for e in (0, 1, 2):
+        assert (tmp_path / 'valid' / f'valid-{e}.ppm').exists()
+    other = MVVNeRFRenderer(32, 512, n_views=1, device=DEV, seed=5)
+    assert other.load(ckpt) and torch.equal(other.fine_net, model.fine_net)
+    assert TN.train_model(model, gen, 2, 1, str(tmp_path), ckpt, valid_data, log=logs.append) == []   # nothing left to do
+    assert len(TN.train_model(model, gen, 3, 1, str(tmp_path), ckpt, valid_data, log=logs.append)) == 1  # resumes at epoch 2

@@ -1,0 +1,205 @@
+"""`train_nerf.py`-shaped training loop on the HIP renderer (reference: src/train_nerf.py).
+
+Same structure and names as the reference script - `compile_model`, `train_model`, `validate`,
+`init_training_session`, `MVNeRFDataGenerator` - with the pieces that are not in this repository's scope
+replaced by explicit stand-ins:
+
+* the dataset submodule (`src/lib/dataset`, absent from the reference tree) -> :class:`SyntheticSceneDataset`,
+  random views with known cameras;
+* the image encoders -> a fixed per-pixel feature map supplied by the dataset (`features`), since
+  `combined_features` is an *input* of the hot path;
+* hydra -> keyword arguments / argparse; cv2 PNG dumps -> binary PPM files.
+
+    python -m thesis_clip_nerf_amd.train_nerf --model-path /tmp/nerf_run --epochs 4 --eval-after 2
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+
+import numpy as np
+import torch
+
+from .model import MVVNeRFRenderer, camera_parameters, render_view
+from .nerf_utils import WarmupScheduler, bbox_biased_sample
+from .synthetic import pinhole, ring_pose
+
+
+class SyntheticSceneDataset:
+    """Stand-in for `load_dataset_nerf(n_perspectives, path)`: `n_scenes` scenes x `n_perspectives` views."""
+
+    def __init__(self, n_scenes=4, n_perspectives=6, height=32, width=32, seed=0):
+        rng = np.random.default_rng(seed)
+        self.n_perspectives = n_perspectives
+        self.k = pinhole(width, height)
+        proj = rng.standard_normal((3, 256)).astype(np.float32)
+        self.colors, self.cameras, self.features = [], [], []
+        for _ in range(n_scenes):
+            base = rng.random((height, width, 3))
+            cols, cams, feats = [], [], []
+            for p in range(n_perspectives):
+                img = np.clip(base + 0.05 * rng.standard_normal(base.shape), 0, 1)
+                cols.append((img * 255).astype(np.uint8))
+                cams.append({'pose': ring_pose(2 * np.pi * p / n_perspectives + rng.uniform(-0.1, 0.1)),
+                             'intrinsics': self.k.reshape(-1).copy()})
+                feats.append(np.tanh((img.astype(np.float32) * 2 - 1) @ proj))
+            self.colors.append(cols)
+            self.cameras.append(cams)
+            self.features.append(feats)
+
+    def __len__(self):
+        return len(self.colors)
+
+
+class MVNeRFDataGenerator:
+    """data_generator/mvnerf.py + base.py: keras-Sequence semantics, NumPy RNG exactly as the reference
+    (np.random.choice of views, bbox_biased_sample of pixels).  Returns ((inputs 5-tuple, features), targets)."""
+
+    def __init__(self, dataset, n_rays_train=512, batch_size=1, n_views=2, shuffle=True):
+        self.dataset = dataset
+        self.n_rays_train = n_rays_train
+        self.batch_size = batch_size
+        self.n_views = n_views
+        self.shuffle = shuffle
+        self.n_perspectives = dataset.n_perspectives
+        self.indices = np.arange(len(dataset))
+        self.on_epoch_end()
+
+    def on_epoch_end(self):
+        if self.shuffle:
+            np.random.shuffle(self.indices)
+
+    def __len__(self):
+        return len(self.indices) // self.batch_size
+
+    def __getitem__(self, index):
+        return self.get_data(self.indices[index * self.batch_size:(index + 1) * self.batch_size])
+
+    def generate_rays(self, color, camera_config):
+        """mvnerf.py:16-25 (u = col, v = row); ray directions via the same float64 formula, on the host."""
+        k = np.reshape(camera_config['intrinsics'], (3, 3)).astype(np.float32)
+        rays = bbox_biased_sample(self.n_rays_train, np.array([0, 0, color.shape[0], color.shape[1]]), color.shape[0],
+                                  color.shape[1])
+        u, v = rays[:, 1], rays[:, 0]
+        pose = camera_config['pose']
+        d = (pose[:3, :3] @ np.linalg.inv(k) @ np.stack((u, v, np.ones_like(u)), axis=0)).T
+        d = d / np.linalg.norm(d, axis=1, keepdims=True)
+        return d, np.broadcast_to(pose[:3, -1], d.shape), rays
+
+    @staticmethod
+    def get_target(color, rays):
+        return np.array(color[rays[:, 0], rays[:, 1], :3]) / 255.0                       # mvnerf.py:45-48
+
+    def get_data(self, batch):
+        ro, rd, imgs, ks, es, feats, targets = [], [], [], [], [], [], []
+        for i in batch:
+            idx = np.random.choice(range(self.n_perspectives), size=self.n_views + 1, replace=False)
+            src, tgt = idx[:-1], idx[-1]
+            r_d, r_o, rays = self.generate_rays(self.dataset.colors[i][tgt], self.dataset.cameras[i][tgt])
+            targets.append(self.get_target(self.dataset.colors[i][tgt], rays))
+            cams = [camera_parameters(self.dataset.cameras[i][s]) for s in src]
+            ro.append(r_o)
+            rd.append(r_d)
+            imgs.append([self.dataset.colors[i][s][..., :3] / 255.0 for s in src])
+            es.append([c[0] for c in cams])
+            ks.append([c[1] for c in cams])
+            feats.append([self.dataset.features[i][s] for s in src])
+        f32 = lambda a: np.array(a, dtype=np.float32)
+        return ((f32(ro), f32(rd), f32(imgs), f32(ks), f32(es)), f32(feats)), f32(targets)
+
+
+def compile_model(nerf_renderer, grad_sync=None):
+    """train_nerf.py:20-34: MSE; Adam with WarmupScheduler(1e-4, 10000, 450000) on the two embeddings."""
+    nerf_renderer.compile(learning_rate=WarmupScheduler(1e-4, 10000, 450000), gradients_clip=1.0, train_readout=False,
+                          grad_sync=grad_sync)
+
+
+def init_training_session(model_log_dir):
+    """utils/util.py:27-37: resume bookkeeping through training_progress.json."""
+    start_epoch = 0
+    training_progress_file = os.path.join(model_log_dir, 'training_progress.json')
+    if os.path.exists(training_progress_file):
+        with open(training_progress_file) as f:
+            start_epoch = json.load(f).get('epoch', 0)
+    return start_epoch, training_progress_file
+
+
+def fit(nerf_renderer, data_generator, epochs, initial_epoch=0, log=print):
+    """Keras `Model.fit(generator, epochs=, initial_epoch=)` over the custom train_step."""
+    history = []
+    for epoch in range(initial_epoch, epochs):
+        losses = []
+        for step in range(len(data_generator)):
+            (inputs, features), targets = data_generator[step]
+            losses.append(nerf_renderer.train_step((inputs, targets), combined_features=features)['loss'])
+        data_generator.on_epoch_end()
+        mean = float(torch.cat(losses).mean()) if losses else float('nan')
+        history.append(mean)
+        log(f'Epoch {epoch + 1}/{epochs} - loss: {mean:.6f}')
+    return history
+
+
+def write_ppm(path, image):
+    with open(path, 'wb') as f:
+        f.write(f'P6 {image.shape[1]} {image.shape[0]} 255\n'.encode())
+        f.write(np.ascontiguousarray(image[..., :3], dtype=np.uint8).tobytes())
+
+
+def validate(nerf_renderer, tgt_color, valid_data):
+    """train_nerf.py:68-81: [sources | target | rendered rgb | rendered depth] side by side."""
+    rgb, depth = render_view(nerf_renderer, **valid_data)
+    src = np.concatenate([c[..., :3] for c in valid_data['src_colors']], axis=1)
+    return np.concatenate([src, tgt_color[..., :3], rgb, np.repeat(depth, 3, axis=2)], axis=1)
+
+
+def train_model(nerf_renderer, data_generator, n_epochs, eval_after_epochs, model_log_dir, model_checkpoint_name, valid_data,
+                log=print):
+    """train_nerf.py:37-65."""
+    start_epoch, training_progress_file = init_training_session(model_log_dir)
+    start_n_fit, n_fits = start_epoch // eval_after_epochs, n_epochs // eval_after_epochs
+    valid_data = dict(valid_data)
+    tgt_color = valid_data.pop('tgt_colors')
+    os.makedirs(f'{model_log_dir}/valid', exist_ok=True)
+    if start_epoch == 0:
+        write_ppm(f'{model_log_dir}/valid/valid-0.ppm', validate(nerf_renderer, tgt_color, valid_data))
+    history = []
+    for k in range(start_n_fit, n_fits):
+        e_epoch = (k + 1) * eval_after_epochs
+        history += fit(nerf_renderer, data_generator, epochs=e_epoch, initial_epoch=k * eval_after_epochs, log=log)
+        write_ppm(f'{model_log_dir}/valid/valid-{e_epoch}.ppm', validate(nerf_renderer, tgt_color, valid_data))
+        with open(training_progress_file, 'w') as f:
+            json.dump({'epoch': e_epoch}, f)
+        nerf_renderer.store(model_checkpoint_name)
+    return history
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument('--model-path', default='/tmp/mvnerf_run')
+    ap.add_argument('--epochs', type=int, default=4)
+    ap.add_argument('--eval-after', type=int, default=2)
+    ap.add_argument('--n-views', type=int, default=1)
+    ap.add_argument('--batch-size', type=int, default=1)
+    ap.add_argument('--n-rays', type=int, default=512)
+    ap.add_argument('--size', type=int, default=32)
+    args = ap.parse_args(argv)
+    train = SyntheticSceneDataset(n_scenes=8, height=args.size, width=args.size, seed=0)
+    valid = SyntheticSceneDataset(n_scenes=1, height=args.size, width=args.size, seed=1)
+    src = list(range(args.n_views))
+    valid_data = {'src_colors': [valid.colors[0][i] for i in src],
+                  'src_camera_configs': [valid.cameras[0][i] for i in src],
+                  'tgt_camera_config': valid.cameras[0][args.n_views],
+                  'tgt_colors': valid.colors[0][args.n_views],
+                  'combined_features': torch.from_numpy(np.array([[valid.features[0][i] for i in src]], dtype=np.float32))}
+    gen = MVNeRFDataGenerator(train, n_rays_train=args.n_rays, batch_size=args.batch_size, n_views=args.n_views)
+    model = MVVNeRFRenderer(args.n_rays, 512, n_views=args.n_views, batch_size=args.batch_size, near=0.3, far=1.3)
+    compile_model(model)
+    ckpt = f'{args.model_path}/model_final'
+    os.makedirs(args.model_path, exist_ok=True)
+    print('Model loaded from checkpoint.' if model.load(ckpt) else 'New model initialized')
+    train_model(model, gen, args.epochs, args.eval_after, args.model_path, ckpt, valid_data)
+
+
+if __name__ == '__main__':
+    main()
