@@ -50,6 +50,7 @@ def main():
     ap.add_argument('--views', type=int, default=1)
     ap.add_argument('--size', type=int, default=64, help='source/target image side (rays = size^2)')
     ap.add_argument('--cpu-rays', type=int, default=512, help='rays of the bounded CPU-baseline sample (0 = skip)')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='bf16: both field passes on the bf16 MFMA kernel (configs 3/5; not the headline)')
     ap.add_argument('--fused-call', action='store_true', help='time mvnerf_render_fwd (one C call) instead of the op sequence')
     args = ap.parse_args()
 
@@ -80,6 +81,9 @@ def main():
     t = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in
          ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'u_coarse', 'u_fine', 'coarse', 'fine']}
     pc, pf = ops.pack_net(t['coarse']), ops.pack_net(t['fine'])
+    bf16 = args.dtype == 'bf16'
+    if bf16:
+        pc16, pf16 = ops.pack_net_bf16(t['coarse']), ops.pack_net_bf16(t['fine'])
     b, r, s = t['u_coarse'].shape
     ws = torch.empty(ops.render_workspace_bytes(b, args.views, r, s), dtype=torch.uint8, device=dev)
     near, far = sc['near'], sc['far']
@@ -89,12 +93,14 @@ def main():
     def step_ops(e=None):
         z = ops.stratified_depths(t['u_coarse'], near, far)
         if e: e[0].record()
-        rgbs_c = ops.field_eval(t['rays_o'], t['rays_d'], z, *field_args, pc)
+        rgbs_c = (ops.field_eval_bf16(t['rays_o'], t['rays_d'], z, *field_args, pc, pc16) if bf16 else
+                  ops.field_eval(t['rays_o'], t['rays_d'], z, *field_args, pc))
         if e: e[1].record()
         rgb, depth, w = ops.composite(z, rgbs_c)
         z_all = ops.resample(z, w, t['u_fine'])
         if e: e[2].record()
-        rgbs_f = ops.field_eval(t['rays_o'], t['rays_d'], z_all, *field_args, pf)
+        rgbs_f = (ops.field_eval_bf16(t['rays_o'], t['rays_d'], z_all, *field_args, pf, pf16) if bf16 else
+                  ops.field_eval(t['rays_o'], t['rays_d'], z_all, *field_args, pf))
         if e: e[3].record()
         fine_rgb, fine_depth, _ = ops.composite(z_all, rgbs_f, return_weights=False)
         return rgb, depth, fine_rgb, fine_depth
@@ -103,7 +109,7 @@ def main():
         return ops.render_fwd(t['rays_o'], t['rays_d'], *field_args, pc, pf, t['u_coarse'], t['u_fine'], near, far,
                               workspace=ws)
 
-    step = step_fused if args.fused_call else step_ops
+    step = step_fused if (args.fused_call and not bf16) else step_ops
     for _ in range(args.warmup):
         out = step()
     barrier()
@@ -121,7 +127,7 @@ def main():
     result = {
         'metric': 'rendered_rays_per_sec', 'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': f'cfg2: _call on B=1 scene/GPU, V={args.views} source view {args.size}x{args.size}x(3+256) fp32, '
                                f'R={r} rays (all pixels of a {args.size}x{args.size} target), 64 coarse + 128 fine samples/ray, '
                                'two 247300-param ResNet-MLPs (379->128, 3+3 blocks), explicit uniforms',
@@ -138,16 +144,18 @@ def main():
             flops_c, flops_f = fps * b * r * s, fps * b * r * 2 * s
             # the fine-pass launch is the dominant kernel instance (2/3 of the FLOPs)
             achieved = flops_f / (fine_ms * 1e-3) / 1e12
+            peak = 2500.0 if bf16 else PEAK_FP32_MFMA_TFLOPS          # dense bf16 MFMA peak ~2.5 PFLOP/s
+            kname = ('field_eval_bf16_kernel' if bf16 else 'field_eval_kernel') + ('<true' if args.views > 1 else '<false') + ('>' if bf16 else ',false>')
             result['roofline'] = {
-                'bound': 'mfma', 'kernel': 'field_eval_kernel<false,false> (fine pass, S=128)' if args.views == 1 else 'field_eval_kernel<true,false> (fine pass, S=128)',
-                'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+                'bound': 'mfma', 'kernel': kname + ' (fine pass, S=128)',
+                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                 'traffic': None, 'flop_per_launch': flops_f, 'avg_launch_ms': fine_ms,
                 'coarse_launch': {'flop_per_launch': flops_c, 'avg_launch_ms': coarse_ms,
                                   'achieved': flops_c / (coarse_ms * 1e-3) / 1e12},
                 'field_kernel_share_of_step': (coarse_ms + fine_ms) / ms_per_step,
             }
             pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and not bf16:
                 try:
                     result['roofline']['traffic'] = json.load(open(pmc)).get('field_eval_fine_hbm_bytes_per_launch')
                 except Exception:

@@ -263,23 +263,42 @@ def _relu(x):
     return np.maximum(x, F32(0.0))
 
 
-def resnet_block(x, w1, b1, w2, b2):
-    """Pre-activation block x + W2.relu(W1.relu(x)+b1)+b2.  Reference: layers.py:262-298."""
-    r = _relu(x) @ w1 + b1
-    r = _relu(r) @ w2 + b2
+def bf16_round(a):
+    """Round fp32 to the nearest bfloat16 (ties to even), returned as fp32 - what v_cvt_pk_bf16_f32 does.
+    Used to restate the bf16 variant of the field pass (bf16 MFMA inputs, fp32 accumulate)."""
+    u = np.ascontiguousarray(a, dtype=F32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(F32).reshape(np.shape(a))
+
+
+def resnet_block(x, w1, b1, w2, b2, rnd=None):
+    """Pre-activation block x + W2.relu(W1.relu(x)+b1)+b2.  Reference: layers.py:262-298.
+    rnd: optional rounding of the matmul inputs (bf16 variant); accumulation, bias and residual stay fp32."""
+    q = rnd if rnd is not None else (lambda a: a)
+    r = q(_relu(x)) @ q(w1) + b1
+    r = q(_relu(r)) @ q(w2) + b2
     return (x + r).astype(F32)
 
 
-def mv_embedding(net, cam_xyz, cam_dir, feat, n_views, complete_output=False):
+def mv_embedding(net, cam_xyz, cam_dir, feat, n_views, complete_output=False, emulate_bf16=False):
     """MVResNetMLPNeRFEmbedding.call.  Reference: layers.py:354-379.
 
     cam_xyz, cam_dir: (B*V,R,S,3); feat: (B*V,R,S,259) -> (B,R,S,128).
+    emulate_bf16: restate the bf16 kernel variant - every Dense input (activations and kernels) rounded to
+    bfloat16 except the PE(cam dir) rows of layer 0, which that kernel keeps in fp32 (per-ray seed).
     """
-    x = np.concatenate([position_encoding(cam_xyz), position_encoding(cam_dir), feat.astype(F32)], axis=-1)
-    x = (x @ net['W0'] + net['b0']).astype(F32)
+    rnd = bf16_round if emulate_bf16 else None
+    if emulate_bf16:
+        pe_xyz, pe_dir = position_encoding(cam_xyz), position_encoding(cam_dir)
+        rest = np.concatenate([pe_xyz, feat.astype(F32)], axis=-1)
+        w_rest = np.concatenate([net['W0'][:60], net['W0'][120:]], axis=0)
+        x = (bf16_round(rest) @ bf16_round(w_rest) + (pe_dir @ net['W0'][60:120] + net['b0'])).astype(F32)
+    else:
+        x = np.concatenate([position_encoding(cam_xyz), position_encoding(cam_dir), feat.astype(F32)], axis=-1)
+        x = (x @ net['W0'] + net['b0']).astype(F32)
     outs = [x]
     for blk in net['blocks'][:N_BLOCKS // 2]:
-        outs.append(resnet_block(outs[-1], *blk))
+        outs.append(resnet_block(outs[-1], *blk, rnd=rnd))
     bv = outs[-1].shape[0]
     pre = outs[-1].reshape(bv // n_views, n_views, *outs[-1].shape[1:])
     fusion = pre[:, 0].copy()
@@ -288,7 +307,7 @@ def mv_embedding(net, cam_xyz, cam_dir, feat, n_views, complete_output=False):
     fusion = (fusion / F32(n_views)).astype(F32)
     outs.append(fusion)
     for blk in net['blocks'][N_BLOCKS // 2:]:
-        outs.append(resnet_block(outs[-1], *blk))
+        outs.append(resnet_block(outs[-1], *blk, rnd=rnd))
     return outs if complete_output else outs[-1]
 
 
@@ -301,9 +320,10 @@ def softplus(x):
     return np.logaddexp(F32(0.0), x.astype(F32)).astype(F32)
 
 
-def render_readout(net, emb):
+def render_readout(net, emb, emulate_bf16=False):
     """RenderReadout.call.  Reference: layers.py:392-397.  -> (rgb (...,3), sigma (...))."""
-    o = (_relu(emb) @ net['Wr'] + net['br']).astype(F32)
+    q = bf16_round if emulate_bf16 else (lambda a: a)
+    o = (q(_relu(emb)) @ q(net['Wr']) + net['br']).astype(F32)
     return sigmoid(o[..., :3]), softplus(o[..., 3])
 
 
@@ -395,7 +415,7 @@ def hierarchical_depths(z_coarse, weights, u_fine, q7_mode=Q7_ZERO, return_indic
 # --------------------------------------------------------------------------------------
 # a15: the forward pass
 # --------------------------------------------------------------------------------------
-def field_eval(net, rays_o, rays_d, zs, images, features, k4, einv, ray_chunk=256, return_taps=False):
+def field_eval(net, rays_o, rays_d, zs, images, features, k4, einv, ray_chunk=256, return_taps=False, emulate_bf16=False):
     """One pass (coarse or fine): project -> gather -> PE -> trunk -> read-out.
 
     Reference: model_v0.py:120-144 (coarse) / :157-180 (fine).  Returns rgb (B,R,S,3), sigma
@@ -419,8 +439,8 @@ def field_eval(net, rays_o, rays_d, zs, images, features, k4, einv, ray_chunk=25
         emb = mv_embedding(net,
                            cam[..., :3].reshape(b * v, rc, s, 3),
                            cdir.reshape(b * v, rc, s, 3),
-                           feat.reshape(b * v, rc, s, -1), v)
-        c, sg = render_readout(net, emb)
+                           feat.reshape(b * v, rc, s, -1), v, emulate_bf16=emulate_bf16)
+        c, sg = render_readout(net, emb, emulate_bf16)
         rgb[:, sl], sigma[:, sl] = c, sg
         if return_taps:
             x0, y0, _, _ = bilinear_taps(pix, h, w)

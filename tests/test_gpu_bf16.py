@@ -1,0 +1,68 @@
+"""bf16 variant of the field pass (BASELINE.json configs 3 / 5): bf16 MFMA inputs, fp32 accumulate.
+Two checks: (1) against the oracle restating exactly that arithmetic (every Dense input rounded to bfloat16,
+fp32 accumulation) - tight, only summation order differs; (2) against the fp32 oracle - the achieved bf16
+error bound that DESIGN.md quotes (this path is not held to the 1e-4 fp32 bar)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mvnerf_oracle as O
+from thesis_clip_nerf_amd import ops
+from thesis_clip_nerf_amd.synthetic import make_scene
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_bf16_round_helper():
+    x = np.array([1.0, 1.00390625, 1.005859375, -2.5, 3.14159274, 1e-30, 0.0], np.float32)
+    t = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+    np.testing.assert_array_equal(O.bf16_round(x), t)
+
+
+@pytest.mark.parametrize('n_views,n_rays,s', [(1, 40, 64), (3, 17, 128), (2, 300, 64)])
+def test_field_eval_bf16(n_views, n_rays, s):
+    sc = make_scene(seed=60 + n_views, n_views=n_views, height=24, width=24, n_rays=n_rays, bias_scale=0.1)
+    d = {k: dev(sc[k]) for k in ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'fine']}
+    rng = np.random.default_rng(0)
+    z = np.sort(rng.uniform(0.3, 1.3, (1, n_rays, s)).astype(np.float32), -1)
+    net = O.unflatten_net(sc['fine'])
+    args = (net, sc['rays_o'], sc['rays_d'], z, sc['images'], sc['features'], sc['intrinsics'], sc['extrinsics_inv'])
+    rgb_e, sig_e, taps_ref = O.field_eval(*args, return_taps=True, emulate_bf16=True)
+    rgb_f, sig_f = O.field_eval(*args)
+    rgbs, taps = ops.field_eval_bf16(d['rays_o'], d['rays_d'], dev(z), d['images'], d['features'], d['intrinsics'],
+                                     d['extrinsics_inv'], ops.pack_net(d['fine']), ops.pack_net_bf16(d['fine']),
+                                     return_taps=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(taps.cpu().numpy(), taps_ref)             # geometry stays fp32 and bit-exact
+    rgbs = rgbs.cpu().numpy()
+    err_e = max(np.abs(rgbs[..., :3] - rgb_e).max(), np.abs(rgbs[..., 3] - sig_e).max())
+    err_f = max(np.abs(rgbs[..., :3] - rgb_f).max(), np.abs(rgbs[..., 3] - sig_f).max())
+    ref_e = np.concatenate([rgb_e, sig_e[..., None]], -1)
+    ref_f = np.concatenate([rgb_f, sig_f[..., None]], -1)
+    mean_e, mean_f = np.abs(rgbs - ref_e).mean(), np.abs(rgbs - ref_f).mean()
+    print(f'bf16 field V={n_views}: vs bf16-restated oracle max {err_e:.2e} mean {mean_e:.2e}; vs fp32 oracle max {err_f:.2e} mean {mean_f:.2e}')
+    # the restated oracle shares every bf16 rounding with the kernel except where a value sits on a rounding boundary
+    # (the kernel's PE recurrence / FMA lerps / summation order differ at the 1e-6 level), so it must be much closer on
+    # average than the fp32 oracle, while single samples can still differ by one bf16 step somewhere upstream
+    assert mean_e < 0.35 * mean_f and err_e < 2e-2
+    assert err_f < 5e-2            # achieved bf16 bound vs fp32
+
+
+def test_render_fwd_bf16_close_to_fp32():
+    sc = make_scene(seed=70, height=32, width=32, n_rays=128, bias_scale=0.05)
+    d = {k: dev(sc[k]) for k in ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'u_coarse', 'u_fine',
+                                 'coarse', 'fine']}
+    ref = O.render_call(O.unflatten_net(sc['coarse']), O.unflatten_net(sc['fine']), sc['rays_o'], sc['rays_d'], sc['images'],
+                        sc['intrinsics'], sc['extrinsics_inv'], sc['features'], sc['near'], sc['far'], 64, sc['u_coarse'], sc['u_fine'])
+    got = ops.render_fwd_bf16(d['rays_o'], d['rays_d'], d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'],
+                              ops.pack_net(d['coarse']), ops.pack_net(d['fine']), ops.pack_net_bf16(d['coarse']),
+                              ops.pack_net_bf16(d['fine']), d['u_coarse'], d['u_fine'], sc['near'], sc['far'])
+    for name, g, r in zip(['rgb', 'depth', 'fine_rgb', 'fine_depth'], got, ref):
+        err = np.abs(g.cpu().numpy() - r).max()
+        print(f'render bf16 {name}: max|bf16 - fp32 oracle| = {err:.2e}')
+        assert err < 3e-2, (name, err)

@@ -109,6 +109,37 @@ int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, 
     return hip_status(mvnerf::launch_field_eval(p, static_cast<hipStream_t>(stream)), "mvnerf_field_eval");
 }
 
+size_t mvnerf_packed_net_bf16_bytes(void) { return (size_t)472 * 1024; }
+
+int mvnerf_pack_net_bf16(const float* net_keras, void* packed16, mvnerf_stream_t stream) {
+    if (!net_keras || !packed16) return fail(MVNERF_E_ARG, "mvnerf_pack_net_bf16: null pointer");
+    if (!aligned16(packed16)) return fail(MVNERF_E_ALIGN, "mvnerf_pack_net_bf16: packed16 must be 16-byte aligned");
+    return hip_status(mvnerf::launch_pack_net_bf16(net_keras, packed16, static_cast<hipStream_t>(stream)), "mvnerf_pack_net_bf16");
+}
+
+int mvnerf_field_eval_bf16(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                           const float* features, const float* intrinsics, const float* extrinsics_inv,
+                           const float* packed_net, const void* packed16, int B, int V, int R, int S, int H, int W,
+                           float* rgbs, int32_t* tap_idx, float* embedding, void* workspace, mvnerf_stream_t stream) {
+    if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !packed_net || !packed16 || !rgbs || !workspace)
+        return fail(MVNERF_E_ARG, "mvnerf_field_eval_bf16: null pointer");
+    if (B <= 0 || V <= 0 || R <= 0 || S <= 0) return fail(MVNERF_E_ARG, "mvnerf_field_eval_bf16: B=%d V=%d R=%d S=%d", B, V, R, S);
+    if (H < 2 || W < 2) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_bf16: source image %dx%d, need H,W >= 2", H, W);
+    const long total = (long)B * R * S;
+    if (total >= (1L << 31) || (long)B * V * H * W >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_bf16: sizes too large for int32 indices");
+    if (!aligned16(features) || !aligned16(packed_net) || !aligned16(packed16) || !aligned16(rgbs) || (tap_idx && !aligned16(tap_idx)) ||
+        (embedding && !aligned16(embedding)) || !aligned16(workspace))
+        return fail(MVNERF_E_ALIGN, "mvnerf_field_eval_bf16: features, packed nets, rgbs, tap_idx, embedding, workspace must be 16-byte aligned");
+    mvnerf::FieldParams p = {};
+    p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.images = images; p.features = features;
+    p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs; p.tap_idx = tap_idx; p.embedding = embedding;
+    p.dir_bias = static_cast<float*>(workspace);
+    p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W;
+    p.total = total;
+    p.n_tiles = (total + 31) / 32;
+    return hip_status(mvnerf::launch_field_eval_bf16(p, packed16, static_cast<hipStream_t>(stream)), "mvnerf_field_eval_bf16");
+}
+
 int mvnerf_composite(const float* z, const float* rgbs, int n_rays, int S, float* rgb, float* depth, float* weights,
                      mvnerf_stream_t stream) {
     if (!z || !rgbs || !rgb || !depth) return fail(MVNERF_E_ARG, "mvnerf_composite: null pointer");

@@ -459,6 +459,12 @@ std::atomic<unsigned> g_launch_seq{0};
 std::mutex g_dev_mutex;
 }  // namespace
 
+hipError_t launch_dir_bias(const FieldParams& p, hipStream_t stream) {
+    const long rows = (long)p.B * p.V * p.R;
+    hipLaunchKernelGGL(dir_bias_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_field_eval(const FieldParams& p_in, hipStream_t stream) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -489,10 +495,7 @@ hipError_t launch_field_eval(const FieldParams& p_in, hipStream_t stream) {
     p.tile_counter = di.counters + (g_launch_seq.fetch_add(1) % kCounterSlots);
     if ((e = hipMemsetAsync(p.tile_counter, 0, sizeof(unsigned int), stream)) != hipSuccess) return e;
 #endif
-    {
-        const long rows = (long)p.B * p.V * p.R;
-        hipLaunchKernelGGL(dir_bias_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
-    }
+    if ((e = launch_dir_bias(p, stream)) != hipSuccess) return e;
     const int waves = p.V > 1 ? 4 : MV_WAVES;
     const long want = (p.n_tiles + waves - 1) / waves;
     const long resident = (long)di.cus * (p.V > 1 ? 1 : 8 / MV_WAVES);   // workgroups that fit at once

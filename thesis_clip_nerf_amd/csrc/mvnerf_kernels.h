@@ -35,6 +35,9 @@ struct FieldParams {
 
 hipError_t launch_pack_net(const float* net_keras, float* packed, hipStream_t stream);
 hipError_t launch_field_eval(const FieldParams& p, hipStream_t stream);
+hipError_t launch_dir_bias(const FieldParams& p, hipStream_t stream);
+hipError_t launch_pack_net_bf16(const float* net_keras, void* packed16, hipStream_t st);
+hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hipStream_t stream);
 
 hipError_t launch_get_rays(const double* m9, const double* origin3, const float* u, const float* v, int n_rays,
                            int width, int normalize, float* rays_o, float* rays_d, double* rays_d64,

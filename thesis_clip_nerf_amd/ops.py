@@ -467,3 +467,55 @@ def adam_clip(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, clip=1.
         rc = _lib.lib().mvnerf_adam_clip(_p(param), _p(grad), _p(m), _p(v), param.numel(), float(lr_t), float(beta1),
                                          float(beta2), float(eps), float(clip), _p(update_mask), _stream(param))
     _lib.check(rc, 'adam_clip')
+
+
+# ---- bf16 variant of the field pass (configs 3 / 5) ---------------------------------------------------------
+def pack_net_bf16(net_keras):
+    """Keras-order fp32 MLP -> bf16 MFMA operand stream (uint8 tensor of mvnerf_packed_net_bf16_bytes())."""
+    _chk(net_keras, 'net_keras', shape=(NET_PARAMS,))
+    out = torch.empty(int(_lib.lib().mvnerf_packed_net_bf16_bytes()), dtype=torch.uint8, device=net_keras.device)
+    with torch.cuda.device(net_keras.device):
+        _lib.check(_lib.lib().mvnerf_pack_net_bf16(_p(net_keras), _p(out), _stream(net_keras)), 'pack_net_bf16')
+    return out
+
+
+def field_eval_bf16(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, packed16, return_taps=False,
+                    return_embedding=False):
+    """mvnerf_field_eval_bf16: as field_eval with the Dense layers on the bf16 MFMA path."""
+    _chk(rays_o, 'rays_o', shape=(None, None, 3))
+    b, r, _ = rays_o.shape
+    _chk(rays_d, 'rays_d', shape=(b, r, 3))
+    _chk(z, 'z', shape=(b, r, None))
+    s = z.shape[2]
+    _chk(images, 'images', shape=(b, None, None, None, 3))
+    _, v, h, w, _ = images.shape
+    _chk(features, 'features', shape=(b, v, h, w, 256))
+    _chk(intrinsics, 'intrinsics', shape=(b, v, 4, 4))
+    _chk(extrinsics_inv, 'extrinsics_inv', shape=(b, v, 4, 4))
+    _chk(packed_net, 'packed_net', shape=(packed_net_floats(),))
+    _chk(packed16, 'packed16', dtype=torch.uint8, shape=(int(_lib.lib().mvnerf_packed_net_bf16_bytes()),))
+    dev = rays_o.device
+    rgbs = torch.empty((b, r, s, 4), dtype=torch.float32, device=dev)
+    taps = torch.empty((b, v, r, s, 4), dtype=torch.int32, device=dev) if return_taps else None
+    emb = torch.empty((b, r, s, 128), dtype=torch.float32, device=dev) if return_embedding else None
+    ws = torch.empty(int(_lib.lib().mvnerf_field_workspace_bytes(b, v, r)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().mvnerf_field_eval_bf16(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(intrinsics),
+                                               _p(extrinsics_inv), _p(packed_net), _p(packed16), b, v, r, s, h, w, _p(rgbs),
+                                               _p(taps), _p(emb), _p(ws), _stream(rays_o))
+    _lib.check(rc, 'field_eval_bf16')
+    out = (rgbs,) + ((taps,) if return_taps else ()) + ((emb,) if return_embedding else ())
+    return out if len(out) > 1 else rgbs
+
+
+def render_fwd_bf16(rays_o, rays_d, images, features, intrinsics, extrinsics_inv, packed_coarse, packed_fine, packed16_coarse,
+                    packed16_fine, u_coarse, u_fine, near, far, q7_mode=Q7_ZERO):
+    """`_call` with both field passes on the bf16 path (sampling, compositing and resampling stay fp32)."""
+    geo = (images, features, intrinsics, extrinsics_inv)
+    z = stratified_depths(u_coarse, near, far)
+    rgbs_c = field_eval_bf16(rays_o, rays_d, z, *geo, packed_coarse, packed16_coarse)
+    rgb, depth, w = composite(z, rgbs_c)
+    z_all = resample(z, w, u_fine, q7_mode)
+    rgbs_f = field_eval_bf16(rays_o, rays_d, z_all, *geo, packed_fine, packed16_fine)
+    fine_rgb, fine_depth, _ = composite(z_all, rgbs_f, return_weights=False)
+    return rgb, depth, fine_rgb, fine_depth
