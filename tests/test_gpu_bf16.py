@@ -66,3 +66,18 @@ def test_render_fwd_bf16_close_to_fp32():
         err = np.abs(g.cpu().numpy() - r).max()
         print(f'render bf16 {name}: max|bf16 - fp32 oracle| = {err:.2e}')
         assert err < 3e-2, (name, err)
+
+
+def test_renderer_compute_dtype_bf16():
+    from thesis_clip_nerf_amd import MVVNeRFRenderer
+    sc = make_scene(seed=71, height=16, width=16, n_rays=64, bias_scale=0.05)
+    inputs = tuple(sc[k] for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'])
+    outs = {}
+    for dt in ('f32', 'bf16'):
+        m = MVVNeRFRenderer(64, 64, n_views=1, near=sc['near'], far=sc['far'], device=DEV, compute_dtype=dt)
+        m.set_weights(sc['coarse'], sc['fine'])
+        outs[dt] = m._call(inputs, 64, 1, sc['features'], u_coarse=dev(sc['u_coarse']), u_fine=dev(sc['u_fine']))
+    for a, b in zip(outs['f32'], outs['bf16']):
+        assert float((a - b).abs().max()) < 3e-2 and not torch.equal(a, b)
+    with pytest.raises(ValueError):
+        MVVNeRFRenderer(64, 64, compute_dtype='fp8')

@@ -146,7 +146,10 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char* stage = smem16 + 65536 + wave * (32 * kStage16Row);   // 8 KiB per wave
-    const float* __restrict__ net = p.net;                               // fp32 image: biases in accumulator order
+    // all biases (accumulator order, fp32) live in LDS for the whole kernel: a global bias load in the middle of a
+    // segment would make the in-order vmcnt wait drain the weight prefetch issued just before it
+    float* net = reinterpret_cast<float*>(smem16 + 65536 + 8 * 32 * kStage16Row) - kPackB0;   // net[kPackB0 + i] -> LDS
+    for (int i = tid; i < kPackBr + 8 - kPackB0; i += 512) net[kPackB0 + i] = p.net[kPackB0 + i];
 
     SegRegs sr;
     seg_prefetch(sr, w16, 0, tid);
@@ -190,8 +193,18 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
 
             // ---- segment 0: PE(cam xyz) + rgb k-steps ----
             const int nxt0 = 1;
+            bias_acc<false>(p.dir_bias + 128 * ((long)bv * p.R + (ray - b * p.R)), h, x);   // global: before the prefetch
+            float rgbv[3];
+            {
+                const float* img = p.images + 3 * (long)tl;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float a = img[c] * 2.0f - 1.0f, bq = img[3 + c] * 2.0f - 1.0f;
+                    const float cq = img[3 * p.W + c] * 2.0f - 1.0f, dq = img[3 * p.W + 3 + c] * 2.0f - 1.0f;
+                    rgbv[c] = bilerp(a, bq, cq, dq, tp.ax, tp.ay);
+                }
+            }
             seg_prefetch(sr, w16, nxt0, tid);
-            bias_acc<false>(p.dir_bias + 128 * ((long)bv * p.R + (ray - b * p.R)), h, x);
             float pe[32];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
@@ -210,18 +223,8 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
                     pe[d * 10 + k] = h ? ck : sk;
                 }
             }
-            {
-                const float* img = p.images + 3 * (long)tl;
-                float rgbv[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float a = img[c] * 2.0f - 1.0f, bq = img[3 + c] * 2.0f - 1.0f;
-                    const float cq = img[3 * p.W + c] * 2.0f - 1.0f, dq = img[3 * p.W + 3 + c] * 2.0f - 1.0f;
-                    rgbv[c] = bilerp(a, bq, cq, dq, tp.ax, tp.ay);
-                }
-                pe[30] = h ? rgbv[1] : rgbv[0];
-                pe[31] = h ? 0.0f : rgbv[2];
-            }
+            pe[30] = h ? rgbv[1] : rgbv[0];
+            pe[31] = h ? 0.0f : rgbv[2];
             {
                 const f32x4* wb = cur ? wbuf1 : wbuf0;
 #pragma unroll
@@ -366,7 +369,7 @@ hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hi
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-    const int lds_bytes = 65536 + 8 * 32 * kStage16Row;
+    const int lds_bytes = 65536 + 8 * 32 * kStage16Row + (kPackBr + 8 - kPackB0) * 4;
     {
         std::lock_guard<std::mutex> lock(mtx);
         if (!attr_done[dev]) {

@@ -37,7 +37,7 @@ class MVVNeRFRenderer:
 
     def __init__(self, n_rays_train, n_rays_infer, n_views=2, n_samples=64, n_features=256,
                  embed_direction_vector=True, batch_size=1, near=0.7, far=1.5, original_image_size=(480, 640),
-                 device='cuda', seed=0, feature_encoder=None, q7_mode=Q7_ZERO):
+                 device='cuda', seed=0, feature_encoder=None, q7_mode=Q7_ZERO, compute_dtype='f32'):
         if n_features != 256:
             raise ValueError('n_features must be 256 (the HIP kernels are built for the reference feature width)')
         if not embed_direction_vector:
@@ -56,10 +56,14 @@ class MVVNeRFRenderer:
         self.device = torch.device(device)
         self.feature_encoder = feature_encoder
         self.q7_mode = q7_mode
+        if compute_dtype not in ('f32', 'bf16'):
+            raise ValueError("compute_dtype must be 'f32' (reference precision) or 'bf16' (bf16 MFMA inputs, fp32 accumulate)")
+        self.compute_dtype = compute_dtype       # inference only; training always runs the fp32 path
         rng = np.random.default_rng(seed)
         self.coarse_net = torch.from_numpy(glorot_net(rng)).to(self.device)      # Keras glorot_uniform, zero bias
         self.fine_net = torch.from_numpy(glorot_net(rng)).to(self.device)
         self._packed = None
+        self._packed16 = None
         self._packed_bwd = None
         self._workspace = None
 
@@ -83,7 +87,14 @@ class MVVNeRFRenderer:
     def packed(self):
         if self._packed is None:
             self._packed = (ops.pack_net(self.coarse_net), ops.pack_net(self.fine_net))
+            self._packed16 = None
         return self._packed
+
+    def packed16(self):
+        self.packed()
+        if self._packed16 is None:
+            self._packed16 = (ops.pack_net_bf16(self.coarse_net), ops.pack_net_bf16(self.fine_net))
+        return self._packed16
 
     # ---- forward -------------------------------------------------------------------------
     def encode(self, image):
@@ -111,6 +122,10 @@ class MVVNeRFRenderer:
             raise ValueError(f'ray_origins: shape {tuple(rays_o.shape)}, expected ({batch_size}, {n_rays}, 3)')
         u_coarse, u_fine = self._uniforms(batch_size, n_rays, u_coarse, u_fine, generator)
         pc, pf = self.packed()
+        if self.compute_dtype == 'bf16':
+            pc16, pf16 = self.packed16()
+            return ops.render_fwd_bf16(rays_o, rays_d, images, features, k4, einv, pc, pf, pc16, pf16, self._dev(u_coarse),
+                                       self._dev(u_fine), self.near, self.far, self.q7_mode)
         need = ops.render_workspace_bytes(batch_size, images.shape[1], n_rays, self.n_samples)
         if self._workspace is None or self._workspace.numel() < need:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
