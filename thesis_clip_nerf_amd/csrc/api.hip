@@ -109,7 +109,7 @@ int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, 
     return hip_status(mvnerf::launch_field_eval(p, static_cast<hipStream_t>(stream)), "mvnerf_field_eval");
 }
 
-size_t mvnerf_packed_net_bf16_bytes(void) { return (size_t)472 * 1024; }
+size_t mvnerf_packed_net_bf16_bytes(void) { return (size_t)480 * 1024; }
 
 int mvnerf_pack_net_bf16(const float* net_keras, void* packed16, mvnerf_stream_t stream) {
     if (!net_keras || !packed16) return fail(MVNERF_E_ARG, "mvnerf_pack_net_bf16: null pointer");

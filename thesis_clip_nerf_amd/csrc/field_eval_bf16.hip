@@ -4,9 +4,10 @@
 //  * v_mfma_f32_32x32x16_bf16 runs 16x faster than the fp32 MFMA, so a wave can no longer stream its own
 //    copy of the weights from L2 (that would need > 64 B/clk/CU of L1 bandwidth).  A 512-thread workgroup
 //    (8 waves = 8 tiles of 32 samples, one workgroup per CU, persistent over tile groups) shares them:
-//    the bf16 weight stream is cut into segments of <= 32 KiB that are double-buffered in LDS; while the waves
-//    run the MFMAs of segment i out of one buffer, all 512 threads have the global loads of segment i+1 in
-//    flight and drop them into the other buffer, one workgroup barrier per segment (16 per tile group).
+//    the bf16 weight stream is cut into 16 KiB segments (4 k-steps x 4 output blocks) that travel through a
+//    ring of 5 LDS buffers by LDS-DMA (global_load_lds_dwordx4, no VGPR staging): while the waves run the MFMAs
+//    of segment i, the loads of segments i+1..i+3 are in flight (a segment's MFMAs last about one L2 round
+//    trip, so a distance of 1 leaves the latency exposed); one counted vmcnt + workgroup barrier per segment.
 //  * activations stay fp32 in the accumulators (residual path, biases, read-out in fp32) and are rounded to
 //    bf16 only when a register block is fed as the next MFMA's B operand (v_cvt_pk_bf16_f32); gathered
 //    features are lerped in fp32, rounded once, and transposed through a wave-private bf16 LDS image.
@@ -31,7 +32,8 @@ using f32x8 = __attribute__((ext_vector_type(8))) float;
 //             (= accumulator registers 8s..8s+7 of block kb fed as B operand), 32 chunks per layer
 //   read-out: 8 chunks, output rows >= 4 zero
 constexpr int kW16ChunkElems = 512;
-constexpr int kW16L0 = 0, kW16Hidden = 80, kW16Readout = 80 + 12 * 32, kW16Chunks = kW16Readout + 8;
+constexpr int kW16Hidden = 80, kW16Readout = 80 + 12 * 32;
+constexpr int kW16Chunks = kW16Readout + 16;      // read-out: 8 chunks + 8 of padding so every segment is 16 chunks
 
 __global__ void pack_net_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,7 +59,7 @@ __global__ void pack_net_bf16_kernel(const float* __restrict__ src, __bf16* __re
         const int f = 32 * (kbs / 2) + 16 * (kbs % 2) + 8 * (jj >> 2) + 4 * h + (jj & 3);
         const int wsrc = kKerasBlocks + (layer / 2) * kKerasBlockStride + (layer % 2) * (kHidden * kHidden + kHidden);
         val = src[wsrc + f * kHidden + 32 * nb + i];
-    } else {
+    } else if (chunk < kW16Readout + 8) {
         const int kbs = chunk - kW16Readout;
         const int f = 32 * (kbs / 2) + 16 * (kbs % 2) + 8 * (jj >> 2) + 4 * h + (jj & 3);
         if (i < 4) val = src[kKerasWr + f * 4 + i];
@@ -71,28 +73,49 @@ hipError_t launch_pack_net_bf16(const float* net_keras, void* packed16, hipStrea
     return hipGetLastError();
 }
 
-// ---- segments of the stream (start chunk, chunks); order per tile: per view 0..8, then 9..15 ----
-__device__ __forceinline__ int seg_start(int s) { return s == 0 ? 0 : (s == 1 ? 16 : (s == 2 ? 48 : (s < 15 ? kW16Hidden + 32 * (s - 3) : kW16Readout))); }
-__device__ __forceinline__ int seg_chunks(int s) { return s == 0 ? 16 : (s == 15 ? 8 : 32); }
+// ---- the segment ring ----------------------------------------------------------------------------------------
+// Per tile the waves consume, for every view, segments q = 0..16 (layer 0: PE+rgb, 4 quarter passes of the
+// features; 3 per-view blocks = 12 half layers) and then q = 17..29 (3 fusion blocks, read-out).  Position p in
+// [0, P = 17V + 13) -> q -> first chunk.  The weights are the same for every tile, so positions wrap modulo P.
+constexpr int kRing = 5, kAhead = 3, kSegF4 = 1024;            // 5 x 16 KiB; float4 per segment
 
-struct SegRegs {
-    f32x4 r[4];
+struct Ring {
+    const f32x4* w16;
+    f32x4* base;        // LDS
+    int c;              // ring slot of the current segment
+    int p, P, V;
+    int tid, wave;
 };
 
-__device__ __forceinline__ void seg_prefetch(SegRegs& sr, const f32x4* __restrict__ w16, int seg, int tid) {
-    const f32x4* src = w16 + (long)seg_start(seg) * 64 + tid;
-    const int per_thread = seg_chunks(seg) / 8;             // 1, 2 or 4 float4 per thread (512 threads)
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-        if (m < per_thread) sr.r[m] = src[512 * m];
+__device__ __forceinline__ int ring_start_chunk(int p, int V) {
+    const int q = p < 17 * V ? p % 17 : 17 + (p - 17 * V);
+    return q < 5 ? 16 * q : (q < 29 ? kW16Hidden + 16 * (q - 5) : kW16Readout);
 }
 
-__device__ __forceinline__ void seg_commit(const SegRegs& sr, f32x4* buf, int seg, int tid) {
-    const int per_thread = seg_chunks(seg) / 8;
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-        if (m < per_thread) buf[tid + 512 * m] = sr.r[m];
-    __syncthreads();                                        // segment visible; previous buffer free for the next one
+// issue the LDS-DMA of position p + ahead into slot (c + ahead) % kRing: 2 x 16 B per thread, 1 KiB per wave-instruction
+__device__ __forceinline__ void ring_issue(const Ring& r, int ahead) {
+    int pp = r.p + ahead;
+    if (pp >= r.P) pp -= r.P;
+    const f32x4* src = r.w16 + (long)ring_start_chunk(pp, r.V) * 64 + r.tid;
+    f32x4* dst = r.base + ((r.c + ahead) % kRing) * kSegF4 + 64 * r.wave;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 512),
+                                     (__attribute__((address_space(3))) void*)(dst + 512), 16, 0, 0);
+}
+
+__device__ __forceinline__ const f32x4* ring_cur(const Ring& r) { return r.base + r.c * kSegF4; }
+
+// end of a segment: the next segment's DMA (issued kAhead - 1 segments ago) must have landed for every wave.
+// kDrain = false leaves the two younger segments (4 DMA instructions of this thread) in flight; segments that also
+// issue ordinary loads or stores drain everything (their own waits are in-order with the DMA anyway).
+template <bool kDrain>
+__device__ __forceinline__ void ring_next(Ring& r) {
+    if (kDrain) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    r.c = r.c + 1 == kRing ? 0 : r.c + 1;
+    r.p = r.p + 1 == r.P ? 0 : r.p + 1;
+    ring_issue(r, kAhead);          // slot (c + 3) % 5 was last read two segments ago; everyone is past that barrier
 }
 
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -115,12 +138,17 @@ __device__ __forceinline__ bf16x8 relu_to_bf16(const f32x16& v, int s) {
     return __builtin_convertvector(t, bf16x8);
 }
 
-// acc += W^T relu(in) for one hidden layer whose 32 chunks sit in wbuf
-__device__ __forceinline__ void dense128_bf16(const f32x4* wbuf, int lane, const f32x16 (&in)[4], f32x16 (&acc)[4]) {
+// acc += W^T relu(in) for one hidden layer = two 16-chunk segments (input blocks 0,1 then 2,3)
+__device__ __forceinline__ void dense128_bf16(Ring& ring, int lane, const f32x16 (&in)[4], f32x16 (&acc)[4]) {
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+    for (int half = 0; half < 2; ++half) {
+        const f32x4* wb = ring_cur(ring);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) step16(wbuf, kb * 2 + s, lane, relu_to_bf16(in[kb], s), acc);
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) step16(wb, kk * 2 + s, lane, relu_to_bf16(in[2 * half + kk], s), acc);
+        ring_next<false>(ring);
+    }
 }
 
 template <bool kAdd>
@@ -141,20 +169,29 @@ constexpr int kStage16Row = 256;      // bytes per staged sample row: 128 channe
 template <bool kMultiView>
 __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, const f32x4* __restrict__ w16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
-    f32x4* wbuf0 = reinterpret_cast<f32x4*>(smem16);                    // 2 x 32 KiB weight segments
-    f32x4* wbuf1 = wbuf0 + 2048;
+    constexpr int kRingBytes = kRing * kSegF4 * 16;                       // 80 KiB
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned char* stage = smem16 + 65536 + wave * (32 * kStage16Row);   // 8 KiB per wave
+    unsigned char* stage = smem16 + kRingBytes + wave * (32 * kStage16Row);   // 8 KiB per wave
     // all biases (accumulator order, fp32) live in LDS for the whole kernel: a global bias load in the middle of a
-    // segment would make the in-order vmcnt wait drain the weight prefetch issued just before it
-    float* net = reinterpret_cast<float*>(smem16 + 65536 + 8 * 32 * kStage16Row) - kPackB0;   // net[kPackB0 + i] -> LDS
+    // segment would make the in-order vmcnt wait drain the weight prefetch issued before it
+    float* net = reinterpret_cast<float*>(smem16 + kRingBytes + 8 * 32 * kStage16Row) - kPackB0;   // net[kPackB0 + i] -> LDS
     for (int i = tid; i < kPackBr + 8 - kPackB0; i += 512) net[kPackB0 + i] = p.net[kPackB0 + i];
 
-    SegRegs sr;
-    seg_prefetch(sr, w16, 0, tid);
-    seg_commit(sr, wbuf0, 0, tid);
-    int cur = 0;                                                         // buffer holding the current segment
+    Ring ring;
+    ring.w16 = w16;
+    ring.base = reinterpret_cast<f32x4*>(smem16);
+    ring.c = 0;
+    ring.p = 0;
+    ring.V = p.V;
+    ring.P = 17 * p.V + 13;
+    ring.tid = tid;
+    ring.wave = wave;
+    ring_issue(ring, 0);
+    ring_issue(ring, 1);
+    ring_issue(ring, 2);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    ring_issue(ring, kAhead);
 
     const long n_groups = (p.n_tiles + 7) / 8;
     for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
@@ -191,21 +228,21 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
                 *reinterpret_cast<int4*>(p.tap_idx + 4 * vrow) = t4;
             }
 
-            // ---- segment 0: PE(cam xyz) + rgb k-steps ----
-            const int nxt0 = 1;
-            bias_acc<false>(p.dir_bias + 128 * ((long)bv * p.R + (ray - b * p.R)), h, x);   // global: before the prefetch
-            float rgbv[3];
+            // ---- segment: PE(cam xyz) + rgb k-steps ----
+            bias_acc<false>(p.dir_bias + 128 * ((long)bv * p.R + (ray - b * p.R)), h, x);
+            float pe[32];
             {
                 const float* img = p.images + 3 * (long)tl;
+                float rgbv[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float a = img[c] * 2.0f - 1.0f, bq = img[3 + c] * 2.0f - 1.0f;
                     const float cq = img[3 * p.W + c] * 2.0f - 1.0f, dq = img[3 * p.W + 3 + c] * 2.0f - 1.0f;
                     rgbv[c] = bilerp(a, bq, cq, dq, tp.ax, tp.ay);
                 }
+                pe[30] = h ? rgbv[1] : rgbv[0];
+                pe[31] = h ? 0.0f : rgbv[2];
             }
-            seg_prefetch(sr, w16, nxt0, tid);
-            float pe[32];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 const float a0 = cam[d] * 3.14159274101257324f;
@@ -223,10 +260,8 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
                     pe[d * 10 + k] = h ? ck : sk;
                 }
             }
-            pe[30] = h ? rgbv[1] : rgbv[0];
-            pe[31] = h ? 0.0f : rgbv[2];
             {
-                const f32x4* wb = cur ? wbuf1 : wbuf0;
+                const f32x4* wb = ring_cur(ring);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     f32x8 t;
@@ -235,14 +270,11 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
                     step16(wb, ks, lane, __builtin_convertvector(t, bf16x8), x);
                 }
             }
-            seg_commit(sr, cur ? wbuf0 : wbuf1, nxt0, tid);
-            cur ^= 1;
+            ring_next<true>(ring);
 
-            // ---- segments 1, 2: the two 128-channel halves of the gathered features ----
+            // ---- 4 segments: the two 128-channel halves of the gathered features, 4 k-steps per segment ----
 #pragma unroll 1
             for (int hf = 0; hf < 2; ++hf) {
-                const int nxt = hf == 0 ? 2 : 3;
-                seg_prefetch(sr, w16, nxt, tid);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const f32x4* fbase = reinterpret_cast<const f32x4*>(p.features) + hf * 32 + j;
 #pragma unroll 4
@@ -265,34 +297,27 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
                     *reinterpret_cast<bf16x4*>(stage + off) = __builtin_convertvector(o, bf16x4);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const f32x4* wb = cur ? wbuf1 : wbuf0;
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    const int off = j * kStage16Row + (((2 * ks + h) ^ (j & 15)) << 4);
-                    const bf16x8 bq = *reinterpret_cast<const bf16x8*>(stage + off);
-                    step16(wb, ks, lane, bq, x);
+                for (int part = 0; part < 2; ++part) {
+                    const f32x4* wb = ring_cur(ring);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int off = j * kStage16Row + (((2 * (4 * part + ks) + h) ^ (j & 15)) << 4);
+                        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(stage + off);
+                        step16(wb, ks, lane, bq, x);
+                    }
+                    ring_next<true>(ring);
                 }
-                seg_commit(sr, cur ? wbuf0 : wbuf1, nxt, tid);
-                cur ^= 1;
             }
 
-            // ---- segments 3..8: the three per-view ResNet blocks ----
+            // ---- 12 segments: the three per-view ResNet blocks ----
 #pragma unroll 1
             for (int bi = 0; bi < 3; ++bi) {
                 const float* bias1 = net + kPackBHidden + 256 * bi;
-                int nxt = 3 + 2 * bi + 1;
-                seg_prefetch(sr, w16, nxt, tid);
                 bias_acc<false>(bias1, h, hid);
-                dense128_bf16(cur ? wbuf1 : wbuf0, lane, x, hid);
-                seg_commit(sr, cur ? wbuf0 : wbuf1, nxt, tid);
-                cur ^= 1;
-                nxt = 3 + 2 * bi + 2;
-                if (nxt == 9 && v + 1 < p.V) nxt = 0;                    // next view restarts at layer 0
-                seg_prefetch(sr, w16, nxt, tid);
+                dense128_bf16(ring, lane, x, hid);
                 bias_acc<true>(bias1 + 128, h, x);
-                dense128_bf16(cur ? wbuf1 : wbuf0, lane, hid, x);
-                seg_commit(sr, cur ? wbuf0 : wbuf1, nxt, tid);
-                cur ^= 1;
+                dense128_bf16(ring, lane, hid, x);
             }
             if (kMultiView) {
 #pragma unroll
@@ -305,22 +330,14 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
             for (int nb = 0; nb < 4; ++nb) x[nb] = xsum[nb] / nv;
         }
 
-        // ---- segments 9..14: fusion blocks ----
+        // ---- 12 segments: fusion blocks ----
 #pragma unroll 1
         for (int bi = 3; bi < 6; ++bi) {
             const float* bias1 = net + kPackBHidden + 256 * bi;
-            int nxt = 3 + 2 * bi + 1;
-            seg_prefetch(sr, w16, nxt, tid);
             bias_acc<false>(bias1, h, hid);
-            dense128_bf16(cur ? wbuf1 : wbuf0, lane, x, hid);
-            seg_commit(sr, cur ? wbuf0 : wbuf1, nxt, tid);
-            cur ^= 1;
-            nxt = 3 + 2 * bi + 2;
-            seg_prefetch(sr, w16, nxt, tid);
+            dense128_bf16(ring, lane, x, hid);
             bias_acc<true>(bias1 + 128, h, x);
-            dense128_bf16(cur ? wbuf1 : wbuf0, lane, hid, x);
-            seg_commit(sr, cur ? wbuf0 : wbuf1, nxt, tid);
-            cur ^= 1;
+            dense128_bf16(ring, lane, hid, x);
         }
         if (p.embedding && valid) {
             float* e = p.embedding + 128 * g + 4 * h;
@@ -333,13 +350,12 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
                 }
         }
 
-        // ---- segment 15: read-out ----
-        seg_prefetch(sr, w16, 0, tid);                                   // first segment of the next tile group
+        // ---- segment: read-out ----
         f32x16 o;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] = (r < 4) ? net[kPackBr + r] : 0.0f;
         {
-            const f32x4* wb = cur ? wbuf1 : wbuf0;
+            const f32x4* wb = ring_cur(ring);
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -356,9 +372,9 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
             out[3] = softplus_f32(o[3]);
             *reinterpret_cast<f32x4*>(p.rgbs + 4 * g) = out;
         }
-        seg_commit(sr, cur ? wbuf0 : wbuf1, 0, tid);
-        cur ^= 1;
+        ring_next<true>(ring);                                           // stores above: drain
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // DMA still in flight must land before the LDS is released
 }
 
 hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hipStream_t stream) {
@@ -369,7 +385,7 @@ hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hi
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-    const int lds_bytes = 65536 + 8 * 32 * kStage16Row + (kPackBr + 8 - kPackB0) * 4;
+    const int lds_bytes = kRing * kSegF4 * 16 + 8 * 32 * kStage16Row + (kPackBr + 8 - kPackB0) * 4;
     {
         std::lock_guard<std::mutex> lock(mtx);
         if (!attr_done[dev]) {
