@@ -38,8 +38,10 @@ FLOP_PER_SAMPLE_V1 = 491264          # BASELINE.md 3 (2 x 245 632 MAC), one sour
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md, chip-level parameters
 
 
-def flop_per_sample(v):
-    return 2 * (v * (379 * 128 + 6 * 128 * 128) + 6 * 128 * 128 + 128 * 4)
+def flop_per_sample(v, table=False):
+    """MFMA FLOPs per sample: per view Dense 379->128 + 3 blocks, then 3 blocks + read-out.  With the texel table the
+    256 feature rows of layer 0 are not multiplied per sample (they are per texel, in project_texels_kernel)."""
+    return 2 * (v * ((379 - (256 if table else 0)) * 128 + 6 * 128 * 128) + 6 * 128 * 128 + 128 * 4)
 
 
 def main():
@@ -51,6 +53,8 @@ def main():
     ap.add_argument('--size', type=int, default=64, help='source/target image side (rays = size^2)')
     ap.add_argument('--cpu-rays', type=int, default=512, help='rays of the bounded CPU-baseline sample (0 = skip)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='bf16: both field passes on the bf16 MFMA kernel (configs 3/5; not the headline)')
+    ap.add_argument('--texel-table', default='auto', choices=['auto', 'on', 'off'],
+                    help="f32: hoist layer 0's feature rows to a per-texel table rebuilt every step (auto: when R*S >= 2*H*W)")
     ap.add_argument('--fused-call', action='store_true', help='time mvnerf_render_fwd (one C call) instead of the op sequence')
     args = ap.parse_args()
 
@@ -88,26 +92,35 @@ def main():
     ws = torch.empty(ops.render_workspace_bytes(b, args.views, r, s), dtype=torch.uint8, device=dev)
     near, far = sc['near'], sc['far']
     field_args = (t['images'], t['features'], t['intrinsics'], t['extrinsics_inv'])
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
+    use_table = (not bf16) and (args.texel_table == 'on' or (args.texel_table == 'auto' and
+                                                              ops.texel_table_pays(r, s, args.size, args.size)))
+    tables = torch.empty((2, b, args.views, args.size, args.size, 128), dtype=torch.float32, device=dev) if use_table else None
 
     def step_ops(e=None):
+        tab_c = tab_f = None
+        if e: e[4].record()
+        if use_table:                      # inside the step: a new _call brings new feature maps
+            tab_c = ops.project_texels(t['features'], pc, out=tables[0])
+            tab_f = ops.project_texels(t['features'], pf, out=tables[1])
+        if e: e[5].record()
         z = ops.stratified_depths(t['u_coarse'], near, far)
         if e: e[0].record()
         rgbs_c = (ops.field_eval_bf16(t['rays_o'], t['rays_d'], z, *field_args, pc, pc16) if bf16 else
-                  ops.field_eval(t['rays_o'], t['rays_d'], z, *field_args, pc))
+                  ops.field_eval(t['rays_o'], t['rays_d'], z, *field_args, pc, texel_table=tab_c))
         if e: e[1].record()
         rgb, depth, w = ops.composite(z, rgbs_c)
         z_all = ops.resample(z, w, t['u_fine'])
         if e: e[2].record()
         rgbs_f = (ops.field_eval_bf16(t['rays_o'], t['rays_d'], z_all, *field_args, pf, pf16) if bf16 else
-                  ops.field_eval(t['rays_o'], t['rays_d'], z_all, *field_args, pf))
+                  ops.field_eval(t['rays_o'], t['rays_d'], z_all, *field_args, pf, texel_table=tab_f))
         if e: e[3].record()
         fine_rgb, fine_depth, _ = ops.composite(z_all, rgbs_f, return_weights=False)
         return rgb, depth, fine_rgb, fine_depth
 
     def step_fused(e=None):
         return ops.render_fwd(t['rays_o'], t['rays_d'], *field_args, pc, pf, t['u_coarse'], t['u_fine'], near, far,
-                              workspace=ws)
+                              workspace=ws, texel_tables=tables)
 
     step = step_fused if (args.fused_call and not bf16) else step_ops
     for _ in range(args.warmup):
@@ -132,12 +145,14 @@ def main():
                                f'R={r} rays (all pixels of a {args.size}x{args.size} target), 64 coarse + 128 fine samples/ray, '
                                'two 247300-param ResNet-MLPs (379->128, 3+3 blocks), explicit uniforms',
                    'rays_per_gpu': b * r, 'samples_per_ray': [s, 2 * s], 'n_views': args.views,
-                   'call': 'mvnerf_render_fwd' if args.fused_call else 'op sequence (6 C-ABI launches/step)',
+                   'call': 'mvnerf_render_fwd' if args.fused_call else f'op sequence ({8 if use_table else 6} C-ABI launches/step)',
+                   'layer0_features': 'texel table, rebuilt every step' if use_table else 'gathered per sample',
                    'parallelism': f'ray/scene sharding x{world}, no data-path collective'},
     }
 
     if rank == 0:
-        fps = flop_per_sample(args.views)
+        fps = flop_per_sample(args.views, use_table)
+        fps_ref = flop_per_sample(args.views)
         if not args.fused_call:
             coarse_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
             fine_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
@@ -145,7 +160,8 @@ def main():
             # the fine-pass launch is the dominant kernel instance (2/3 of the FLOPs)
             achieved = flops_f / (fine_ms * 1e-3) / 1e12
             peak = 2500.0 if bf16 else PEAK_FP32_MFMA_TFLOPS          # dense bf16 MFMA peak ~2.5 PFLOP/s
-            kname = ('field_eval_bf16_kernel' if bf16 else 'field_eval_kernel') + ('<true' if args.views > 1 else '<false') + ('>' if bf16 else ',false>')
+            kname = (('field_eval_bf16_kernel' if bf16 else 'field_eval_kernel') + ('<true' if args.views > 1 else '<false') +
+                     ('>' if bf16 else (',false,true>' if use_table else ',false,false>')))
             result['roofline'] = {
                 'bound': 'mfma', 'kernel': kname + ' (fine pass, S=128)',
                 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
@@ -154,8 +170,14 @@ def main():
                                   'achieved': flops_c / (coarse_ms * 1e-3) / 1e12},
                 'field_kernel_share_of_step': (coarse_ms + fine_ms) / ms_per_step,
             }
+            if use_table:
+                # `achieved` counts the FLOPs the kernel executes; the reference's graph multiplies the 256 feature
+                # rows per sample, so the same launch stands for more "reference FLOPs" than it runs
+                result['roofline']['reference_flop_per_launch'] = fps_ref * b * r * 2 * s
+                result['roofline']['reference_equiv_tflops'] = fps_ref * b * r * 2 * s / (fine_ms * 1e-3) / 1e12
+                result['roofline']['project_texels_ms_per_step'] = float(np.mean([e[4].elapsed_time(e[5]) for e in ev]))
             pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-            if os.path.exists(pmc) and not bf16:
+            if os.path.exists(pmc) and not bf16 and not use_table:
                 try:
                     result['roofline']['traffic'] = json.load(open(pmc)).get('field_eval_fine_hbm_bytes_per_launch')
                 except Exception:

@@ -95,6 +95,25 @@ int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, 
 /* Bytes of scratch mvnerf_field_eval needs (B*V*R*128 floats: the per-(view, ray) part of layer 0). */
 size_t mvnerf_field_workspace_bytes(int B, int V, int R);
 
+/* ---- Texel table: the feature part of layer 0 hoisted from samples to texels. ----
+ * The first Dense of MVResNetMLPNerfEmbedding (layers.py:357-363) is linear in its input, and the gathered feature
+ * vector (model_v0.py:131-136, tfa interpolate_bilinear) is linear in the four texels it blends, so
+ *     W0[123:379]^T lerp(f_tl, f_tr, f_bl, f_br) == lerp(W0f^T f_tl, W0f^T f_tr, W0f^T f_bl, W0f^T f_br)
+ * up to fp32 rounding (measured: tests/test_gpu_parity.py, same 1e-4 bar as the direct form).  The table holds
+ * W0f^T f for every texel of every source view: (B*V,H,W,128) floats, features in accumulator order.  It depends
+ * on the feature maps and on ONE net's W0 (coarse and fine nets need a table each); it pays off when a table is
+ * used for more samples than it has texels (R*S >= H*W; rendering a frame chunk by chunk re-uses it).
+ * mvnerf_field_eval_table == mvnerf_field_eval with 128 of the 190 layer-0 k-steps replaced by a 128-channel
+ * lerp of table rows; every output, including tap_idx / pix / the activation taps, has the same meaning. */
+size_t mvnerf_texel_table_bytes(int B, int V, int H, int W);
+int mvnerf_project_texels(const float* features, const float* packed_net, int B, int V, int H, int W, float* texel_table,
+                          mvnerf_stream_t stream);
+int mvnerf_field_eval_table(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                            const float* features, const float* texel_table, const float* intrinsics,
+                            const float* extrinsics_inv, const float* packed_net, int B, int V, int R, int S, int H, int W,
+                            float* rgbs, int32_t* tap_idx, float* pix, float* embedding, float* acts_per_view,
+                            float* acts_fused, void* workspace, mvnerf_stream_t stream);
+
 /* ---- bf16 variant of the field pass (BASELINE.json configs 3 and 5: bf16 weights and MFMA inputs, fp32
  * accumulate, fp32 geometry / biases / read-out activations).  Not held to the 1e-4 fp32 bar; the achieved error
  * against the fp32 oracle is stated in DESIGN.md and tests/test_gpu_bf16.py. ---- */
@@ -229,13 +248,16 @@ size_t mvnerf_render_workspace_bytes(int B, int V, int R, int S);
  * u_coarse, u_fine (B,R,S) are the uniforms the reference draws inside the graph
  * (nerf_utils.py:57,151), here explicit.  S must be 64.
  * Outputs: rgb, fine_rgb (B,R,3); depth, fine_depth (B,R)  (the reference's 4-tuple, :184).
- * workspace: 16-byte aligned, mvnerf_render_workspace_bytes(B,V,R,S) bytes. */
+ * workspace: 16-byte aligned, mvnerf_render_workspace_bytes(B,V,R,S) bytes.
+ * texel_tables (optional, may be NULL = gather raw features): 2 x mvnerf_texel_table_bytes(B,V,H,W) bytes, coarse
+ * net's table then fine net's.  tables_ready == 0: both are (re)built by this call; != 0: used as they are (same
+ * feature maps and nets as the call that built them, e.g. the next ray chunk of the same frame). */
 int mvnerf_render_fwd(const float* rays_o, const float* rays_d, const float* images, const float* features,
                       const float* intrinsics, const float* extrinsics_inv, const float* packed_coarse,
                       const float* packed_fine, const float* u_coarse, const float* u_fine, int B, int V,
                       int R, int S, int H, int W, double near_, double far_, int q7_mode, float* rgb,
-                      float* depth, float* fine_rgb, float* fine_depth, void* workspace,
-                      mvnerf_stream_t stream);
+                      float* depth, float* fine_rgb, float* fine_depth, void* workspace, float* texel_tables,
+                      int tables_ready, mvnerf_stream_t stream);
 
 #ifdef __cplusplus
 }

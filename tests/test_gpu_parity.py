@@ -58,6 +58,35 @@ def test_field_eval_matches_oracle(n_views, hw, seed):
     assert np.abs(rgbs[..., 3] - sig_ref).max() < TOL
 
 
+@pytest.mark.parametrize('n_views,hw,seed', [(1, (16, 16), 0), (2, (12, 20), 1), (3, (64, 64), 2)])
+def test_field_eval_texel_table_matches_oracle(n_views, hw, seed):
+    """Layer 0's feature rows hoisted to a per-texel table (mvnerf_project_texels + mvnerf_field_eval_table): same
+    bars as the direct form against the oracle; the table itself against W0[123:379]^T features in float64."""
+    sc = make_scene(seed=seed, height=hw[0], width=hw[1], n_views=n_views, n_rays=48, bias_scale=0.1)
+    d = scene_to_dev(sc)
+    _, z = O.sample_along_ray(sc['rays_o'], sc['rays_d'], sc['near'], sc['far'], 64, sc['u_coarse'])
+    net = O.unflatten_net(sc['coarse'])
+    rgb_ref, sig_ref, taps_ref = O.field_eval(net, sc['rays_o'], sc['rays_d'], z, sc['images'], sc['features'],
+                                              sc['intrinsics'], sc['extrinsics_inv'], return_taps=True)
+    packed = ops.pack_net(d['coarse'])
+    table = ops.project_texels(d['features'], packed)
+    want = sc['features'].astype(np.float64) @ net['W0'][123:].astype(np.float64)              # (B,V,H,W,128)
+    slot = [(((n & 31) >> 2) & 1) * 64 + (n >> 5) * 16 + ((n & 3) + 4 * ((n & 31) >> 3)) for n in range(128)]
+    got_table = table.cpu().numpy()[..., slot]                                                 # accumulator order -> natural
+    assert np.abs(got_table - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+    args = (d['rays_o'], d['rays_d'], dev(z), d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'], packed)
+    rgbs, taps, emb = ops.field_eval(*args, return_taps=True, return_embedding=True, texel_table=table)
+    rgbs_direct, emb_direct = ops.field_eval(*args, return_embedding=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(taps.cpu().numpy(), taps_ref)
+    rgbs = rgbs.cpu().numpy()
+    assert np.abs(rgbs[..., :3] - rgb_ref).max() < TOL
+    assert np.abs(rgbs[..., 3] - sig_ref).max() < TOL
+    # the two forms differ by fp32 re-association only
+    assert (emb - emb_direct).abs().max().item() < 2e-5 * max(1.0, emb_direct.abs().max().item())
+    assert (torch.from_numpy(rgbs).to(DEV) - rgbs_direct).abs().max().item() < 2e-5
+
+
 def test_field_eval_ragged_tail_and_fine_count():
     # total samples not a multiple of the 32-sample wave tile; S = 128 as in the fine pass
     sc = make_scene(seed=4, height=16, width=16, n_rays=3)
@@ -109,8 +138,9 @@ def test_resample_indices_bit_exact(q7):
     assert (np.diff(z_all, axis=-1) >= 0).all()
 
 
+@pytest.mark.parametrize('tables', [None, 'auto'])
 @pytest.mark.parametrize('n_views,seed', [(1, 0), (3, 1)])
-def test_render_fwd_matches_oracle(n_views, seed):
+def test_render_fwd_matches_oracle(n_views, seed, tables):
     sc = make_scene(seed=seed, height=32, width=32, n_views=n_views, n_rays=96, bias_scale=0.05)
     d = scene_to_dev(sc)
     ref = O.render_call(O.unflatten_net(sc['coarse']), O.unflatten_net(sc['fine']), sc['rays_o'], sc['rays_d'],
@@ -118,8 +148,9 @@ def test_render_fwd_matches_oracle(n_views, seed):
                         64, sc['u_coarse'], sc['u_fine'])
     got = ops.render_fwd(d['rays_o'], d['rays_d'], d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'],
                          ops.pack_net(d['coarse']), ops.pack_net(d['fine']), d['u_coarse'], d['u_fine'], sc['near'],
-                         sc['far'])
+                         sc['far'], texel_tables=tables)
     torch.cuda.synchronize()
+    assert tables is None or ops.texel_table_pays(96, 64, 32, 32)
     for name, g, r in zip(['rgb', 'depth', 'fine_rgb', 'fine_depth'], got, ref):
         err = np.abs(g.cpu().numpy() - r).max()
         assert err < TOL, (name, err)

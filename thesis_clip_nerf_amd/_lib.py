@@ -28,6 +28,9 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     'mvnerf_stratified_depths': (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p]),
     'mvnerf_field_eval': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p] * 8),
+    'mvnerf_texel_table_bytes': (c_size_t, [c_int] * 4),
+    'mvnerf_project_texels': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
+    'mvnerf_field_eval_table': (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_void_p] * 8),
     'mvnerf_packed_net_bf16_bytes': (c_size_t, []),
     'mvnerf_pack_net_bf16': (c_int, [c_void_p, c_void_p, c_void_p]),
     'mvnerf_field_eval_bf16': (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_void_p] * 5),
@@ -55,7 +58,8 @@ SIGNATURES = {
     'mvnerf_adam_clip': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float,
                                  c_void_p, c_void_p]),
     'mvnerf_render_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
-    'mvnerf_render_fwd': (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_double, c_double, c_int] + [c_void_p] * 6),
+    'mvnerf_render_fwd': (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_double, c_double, c_int] + [c_void_p] * 6 +
+                          [c_int, c_void_p]),
 }
 
 _lib = None

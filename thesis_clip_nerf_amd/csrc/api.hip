@@ -84,11 +84,12 @@ int mvnerf_stratified_depths(const float* u, int n_rays, int n_samples, double n
                       "mvnerf_stratified_depths");
 }
 
-int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, const float* images,
-                      const float* features, const float* intrinsics, const float* extrinsics_inv,
-                      const float* packed_net, int B, int V, int R, int S, int H, int W, float* rgbs,
-                      int32_t* tap_idx, float* pix, float* embedding, float* acts_per_view, float* acts_fused,
-                      void* workspace, mvnerf_stream_t stream) {
+static int field_eval_impl(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                           const float* features, const float* texel_table, const float* intrinsics,
+                           const float* extrinsics_inv, const float* packed_net, int B, int V, int R, int S, int H, int W,
+                           float* rgbs, int32_t* tap_idx, float* pix, float* embedding, float* acts_per_view,
+                           float* acts_fused, void* workspace, mvnerf_stream_t stream) {
+    if (texel_table && !aligned16(texel_table)) return fail(MVNERF_E_ALIGN, "mvnerf_field_eval_table: texel_table must be 16-byte aligned");
     if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !packed_net || !rgbs || !workspace)
         return fail(MVNERF_E_ARG, "mvnerf_field_eval: null pointer");
     if (B <= 0 || V <= 0 || R <= 0 || S <= 0) return fail(MVNERF_E_ARG, "mvnerf_field_eval: B=%d V=%d R=%d S=%d", B, V, R, S);
@@ -100,13 +101,50 @@ int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, 
         (embedding && !aligned16(embedding)) || (acts_per_view && !aligned16(acts_per_view)) ||
         (acts_fused && !aligned16(acts_fused)) || !aligned16(workspace))
         return fail(MVNERF_E_ALIGN, "mvnerf_field_eval: features, packed_net, rgbs, tap_idx, embedding must be 16-byte aligned");
-    mvnerf::FieldParams p;
+    mvnerf::FieldParams p = {};
+    p.texel_table = texel_table;
     p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.images = images; p.features = features;
     p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs; p.tap_idx = tap_idx; p.pix = pix; p.embedding = embedding; p.acts_view = acts_per_view; p.acts_fused = acts_fused; p.dir_bias = static_cast<float*>(workspace); p.stash = nullptr; p.stash_stride = 0;
     p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W;
     p.total = total;
     p.n_tiles = (total + 31) / 32;
     return hip_status(mvnerf::launch_field_eval(p, static_cast<hipStream_t>(stream)), "mvnerf_field_eval");
+}
+
+int mvnerf_field_eval(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                      const float* features, const float* intrinsics, const float* extrinsics_inv,
+                      const float* packed_net, int B, int V, int R, int S, int H, int W, float* rgbs,
+                      int32_t* tap_idx, float* pix, float* embedding, float* acts_per_view, float* acts_fused,
+                      void* workspace, mvnerf_stream_t stream) {
+    return field_eval_impl(rays_o, rays_d, z, images, features, nullptr, intrinsics, extrinsics_inv, packed_net, B, V, R, S,
+                           H, W, rgbs, tap_idx, pix, embedding, acts_per_view, acts_fused, workspace, stream);
+}
+
+size_t mvnerf_texel_table_bytes(int B, int V, int H, int W) {
+    if (B <= 0 || V <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * V * H * W * 128 * sizeof(float);
+}
+
+int mvnerf_project_texels(const float* features, const float* packed_net, int B, int V, int H, int W, float* texel_table,
+                          mvnerf_stream_t stream) {
+    if (!features || !packed_net || !texel_table) return fail(MVNERF_E_ARG, "mvnerf_project_texels: null pointer");
+    if (B <= 0 || V <= 0 || H < 2 || W < 2) return fail(MVNERF_E_ARG, "mvnerf_project_texels: B=%d V=%d H=%d W=%d", B, V, H, W);
+    if ((long)B * V * H * W >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_project_texels: B*V*H*W too large for int32 indices");
+    if (!aligned16(features) || !aligned16(packed_net) || !aligned16(texel_table))
+        return fail(MVNERF_E_ALIGN, "mvnerf_project_texels: features, packed_net, texel_table must be 16-byte aligned");
+    return hip_status(mvnerf::launch_project_texels(features, packed_net, (long)B * V * H * W, texel_table,
+                                                    static_cast<hipStream_t>(stream)),
+                      "mvnerf_project_texels");
+}
+
+int mvnerf_field_eval_table(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                            const float* features, const float* texel_table, const float* intrinsics,
+                            const float* extrinsics_inv, const float* packed_net, int B, int V, int R, int S, int H, int W,
+                            float* rgbs, int32_t* tap_idx, float* pix, float* embedding, float* acts_per_view,
+                            float* acts_fused, void* workspace, mvnerf_stream_t stream) {
+    if (!texel_table) return fail(MVNERF_E_ARG, "mvnerf_field_eval_table: null texel_table");
+    return field_eval_impl(rays_o, rays_d, z, images, features, texel_table, intrinsics, extrinsics_inv, packed_net, B, V, R,
+                           S, H, W, rgbs, tap_idx, pix, embedding, acts_per_view, acts_fused, workspace, stream);
 }
 
 size_t mvnerf_packed_net_bf16_bytes(void) { return (size_t)480 * 1024; }
@@ -408,7 +446,8 @@ int mvnerf_render_fwd(const float* rays_o, const float* rays_d, const float* ima
                       const float* intrinsics, const float* extrinsics_inv, const float* packed_coarse,
                       const float* packed_fine, const float* u_coarse, const float* u_fine, int B, int V, int R,
                       int S, int H, int W, double near_, double far_, int q7_mode, float* rgb, float* depth,
-                      float* fine_rgb, float* fine_depth, void* workspace, mvnerf_stream_t stream) {
+                      float* fine_rgb, float* fine_depth, void* workspace, float* texel_tables, int tables_ready,
+                      mvnerf_stream_t stream) {
     if (!u_coarse || !u_fine || !rgb || !depth || !fine_rgb || !fine_depth || !workspace || !packed_fine)
         return fail(MVNERF_E_ARG, "mvnerf_render_fwd: null pointer");
     if (S != 64) return fail(MVNERF_E_SHAPE, "mvnerf_render_fwd: S=%d, only the reference's n_samples=64 is built", S);
@@ -418,15 +457,25 @@ int mvnerf_render_fwd(const float* rays_o, const float* rays_d, const float* ima
     if (n_rays * 2 * S >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_render_fwd: B*R*2S too large");
     const Workspace w = carve(workspace, n_rays, V, S);
     int rc;
+    const float *table_c = nullptr, *table_f = nullptr;
+    if (texel_tables) {                                       // [coarse net | fine net], mvnerf_texel_table_bytes each
+        float* tf = texel_tables + mvnerf_texel_table_bytes(B, V, H, W) / sizeof(float);
+        if (!tables_ready) {
+            if ((rc = mvnerf_project_texels(features, packed_coarse, B, V, H, W, texel_tables, stream))) return rc;
+            if ((rc = mvnerf_project_texels(features, packed_fine, B, V, H, W, tf, stream))) return rc;
+        }
+        table_c = texel_tables;
+        table_f = tf;
+    }
     if ((rc = mvnerf_stratified_depths(u_coarse, (int)n_rays, S, near_, far_, w.z, stream))) return rc;
-    if ((rc = mvnerf_field_eval(rays_o, rays_d, w.z, images, features, intrinsics, extrinsics_inv, packed_coarse, B, V,
-                                R, S, H, W, w.rgbs_c, nullptr, nullptr, nullptr, nullptr, nullptr, w.dir_bias, stream)))
+    if ((rc = field_eval_impl(rays_o, rays_d, w.z, images, features, table_c, intrinsics, extrinsics_inv, packed_coarse, B, V,
+                              R, S, H, W, w.rgbs_c, nullptr, nullptr, nullptr, nullptr, nullptr, w.dir_bias, stream)))
         return rc;
     if ((rc = mvnerf_composite(w.z, w.rgbs_c, (int)n_rays, S, rgb, depth, w.weights, stream))) return rc;
     if ((rc = mvnerf_resample(w.z, w.weights, u_fine, (int)n_rays, S, q7_mode, w.z_all, nullptr, nullptr, nullptr, nullptr, stream)))
         return rc;
-    if ((rc = mvnerf_field_eval(rays_o, rays_d, w.z_all, images, features, intrinsics, extrinsics_inv, packed_fine, B,
-                                V, R, 2 * S, H, W, w.rgbs_f, nullptr, nullptr, nullptr, nullptr, nullptr, w.dir_bias, stream)))
+    if ((rc = field_eval_impl(rays_o, rays_d, w.z_all, images, features, table_f, intrinsics, extrinsics_inv, packed_fine, B,
+                              V, R, 2 * S, H, W, w.rgbs_f, nullptr, nullptr, nullptr, nullptr, nullptr, w.dir_bias, stream)))
         return rc;
     return mvnerf_composite(w.z_all, w.rgbs_f, (int)n_rays, 2 * S, fine_rgb, fine_depth, nullptr, stream);
 }

@@ -135,7 +135,10 @@ __device__ __forceinline__ int stage_offset(int row, int chunk) {      // floats
     return row * kStageRow + ((chunk ^ (row & 15)) << 2);
 }
 
-template <bool kMultiView, bool kStash>
+// kProj: the 256 feature rows of layer 0 come from the texel table (project_texels_kernel) instead of 128 k-steps:
+// layer 0 is linear in the gathered features and the bilinear gather is linear in the texels, so
+// W0f^T lerp(taps) = lerp(W0f^T taps); the lerp then runs on 128 projected channels and adds into the accumulators.
+template <bool kMultiView, bool kStash, bool kProj>
 __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, (kMultiView || kStash) ? 1 : 2) void field_eval_kernel(FieldParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];       // 16 KiB per wave
 
@@ -241,10 +244,41 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, (kMultiView || kS
 #pragma unroll
         for (int gq = 0; gq < 8; ++gq) {
             const float bb[4] = {pe[4 * gq], pe[4 * gq + 1], pe[4 * gq + 2], pe[4 * gq + 3]};
+            if (kProj && gq == 7) ws.pos = kPackHidden * 4;           // the stream skips the 32 feature groups
             mfma_step(ws, bb, x);
         }
+        if (kProj) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // earlier reads of `stage` are done
+            const f32x4* tbase = reinterpret_cast<const f32x4*>(p.texel_table) + j;     // 32 float4 per texel row
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int src = 2 * it + h;                           // sample whose 4 table rows this half-wave loads
+                const int tls = __shfl(tl, src);
+                const float axs = __shfl(tp.ax, src), ays = __shfl(tp.ay, src);
+                const f32x4* f = tbase + (long)tls * 32;
+                const f32x4 vtl = f[0], vtr = f[32], vbl = f[(long)p.W * 32], vbr = f[(long)p.W * 32 + 32];
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float top = fmaf(axs, vtr[c] - vtl[c], vtl[c]);
+                    const float bot = fmaf(axs, vbr[c] - vbl[c], vbl[c]);
+                    o[c] = fmaf(ays, bot - top, top);
+                }
+                *reinterpret_cast<f32x4*>(stage + stage_offset(src, j)) = o;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // table rows are in accumulator order [h][nb][r]: chunk 16h + 4nb + q of row j = registers 4q..4q+3 of block nb
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(stage + stage_offset(j, 16 * h + 4 * nb + q));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[nb][4 * q + c] += t4[c];
+                }
+        }
 #pragma unroll 1
-        for (int hf = 0; hf < 2; ++hf) {
+        for (int hf = 0; hf < (kProj ? 0 : 2); ++hf) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // earlier reads of `stage` are done
             const f32x4* fbase = reinterpret_cast<const f32x4*>(p.features) + hf * 32 + j;
 #pragma unroll 4
@@ -383,6 +417,45 @@ __global__ __launch_bounds__(256) void dir_bias_kernel(FieldParams p) {
     out[acc_slot(64 + lane)] = a1;
 }
 
+// ---- texel table: T[b*V+v][y][x][.] = W0[123:379]^T features[b,v,y,x,:] in accumulator order [h][nb][r] ----
+// One wavefront per (32 texels, output block nb): 32 steps of 4 k-steps; A = feature groups 8..39 of the packed
+// layer-0 kernel (chunk (g, nb)), B = this lane's texel, channels 8q + 4h + {0..3} of group q (one float4).
+__global__ __launch_bounds__(256) void project_texels_kernel(const float* __restrict__ features,
+                                                             const float* __restrict__ net, long n_texels,
+                                                             float* __restrict__ table) {
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int nb = threadIdx.x >> 6;
+    long t = (long)blockIdx.x * 32 + j;
+    const bool valid = t < n_texels;
+    if (!valid) t = n_texels - 1;
+    const f32x4* f = reinterpret_cast<const f32x4*>(features) + t * 64 + h;
+    const f32x4* w = reinterpret_cast<const f32x4*>(net) + ((long)kL0GroupFeat * 4 + nb) * 64 + lane;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll 8
+    for (int q = 0; q < 32; ++q) {
+        const f32x4 a = w[(long)q * 256], b = f[2 * q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma(a[e], b[e], acc);
+    }
+    if (valid) {
+        f32x4* out = reinterpret_cast<f32x4*>(table + 128 * t + 64 * h + 16 * nb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            out[q] = v;
+        }
+    }
+}
+
+hipError_t launch_project_texels(const float* features, const float* packed_net, long n_texels, float* table,
+                                 hipStream_t stream) {
+    hipLaunchKernelGGL(project_texels_kernel, dim3((unsigned)((n_texels + 31) / 32)), dim3(256), 0, stream, features,
+                       packed_net, n_texels, table);
+    return hipGetLastError();
+}
+
 // ---- weight packing -------------------------------------------------------------------------
 __global__ void pack_net_kernel(const float* __restrict__ src, float* __restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -478,14 +551,17 @@ hipError_t launch_field_eval(const FieldParams& p_in, hipStream_t stream) {
             if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
             di.cus = prop.multiProcessorCount;
             if ((e = hipGetSymbolAddress(reinterpret_cast<void**>(&di.counters), HIP_SYMBOL(g_tile_counters))) != hipSuccess) return e;
-            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_eval_kernel<false, false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, MV_WAVES * kTile * kStageRow * 4)) != hipSuccess) return e;
-            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_eval_kernel<true, false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTile * kStageRow * 4)) != hipSuccess) return e;
-            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_eval_kernel<true, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTile * kStageRow * 4)) != hipSuccess) return e;
-            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_eval_kernel<false, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, MV_WAVES * kTile * kStageRow * 4)) != hipSuccess) return e;
+            const int lds_sv = MV_WAVES * kTile * kStageRow * 4, lds_mv = 4 * kTile * kStageRow * 4;
+            const struct { const void* fn; int bytes; } kernels[] = {
+                {reinterpret_cast<const void*>(&field_eval_kernel<false, false, false>), lds_sv},
+                {reinterpret_cast<const void*>(&field_eval_kernel<false, false, true>), lds_sv},
+                {reinterpret_cast<const void*>(&field_eval_kernel<false, true, false>), lds_sv},
+                {reinterpret_cast<const void*>(&field_eval_kernel<true, false, false>), lds_mv},
+                {reinterpret_cast<const void*>(&field_eval_kernel<true, false, true>), lds_mv},
+                {reinterpret_cast<const void*>(&field_eval_kernel<true, true, false>), lds_mv},
+            };
+            for (const auto& k : kernels)
+                if ((e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes)) != hipSuccess) return e;
             di.attr_set = true;
         }
     }
@@ -501,17 +577,22 @@ hipError_t launch_field_eval(const FieldParams& p_in, hipStream_t stream) {
     const long resident = (long)di.cus * (p.V > 1 ? 1 : 8 / MV_WAVES);   // workgroups that fit at once
     const unsigned wgs = (unsigned)((MV_PERSIST && want > resident) ? resident : want);
     const size_t lds_bytes = (size_t)waves * kTile * kStageRow * 4;
+    if (p.stash && p.texel_table) return hipErrorInvalidValue;           // the training kernels gather raw features
     if (p.V > 1) {
         if (p.stash) {
             if (((long)p.R * p.S) % 32 != 0) return hipErrorInvalidValue;     // tiles must not straddle scenes
-            hipLaunchKernelGGL((field_eval_kernel<true, true>), dim3(wgs), dim3(256), lds_bytes, stream, p);
+            hipLaunchKernelGGL((field_eval_kernel<true, true, false>), dim3(wgs), dim3(256), lds_bytes, stream, p);
+        } else if (p.texel_table) {
+            hipLaunchKernelGGL((field_eval_kernel<true, false, true>), dim3(wgs), dim3(256), lds_bytes, stream, p);
         } else {
-            hipLaunchKernelGGL((field_eval_kernel<true, false>), dim3(wgs), dim3(256), lds_bytes, stream, p);
+            hipLaunchKernelGGL((field_eval_kernel<true, false, false>), dim3(wgs), dim3(256), lds_bytes, stream, p);
         }
     } else if (p.stash) {
-        hipLaunchKernelGGL((field_eval_kernel<false, true>), dim3(wgs), dim3(64 * MV_WAVES), lds_bytes, stream, p);
+        hipLaunchKernelGGL((field_eval_kernel<false, true, false>), dim3(wgs), dim3(64 * MV_WAVES), lds_bytes, stream, p);
+    } else if (p.texel_table) {
+        hipLaunchKernelGGL((field_eval_kernel<false, false, true>), dim3(wgs), dim3(64 * MV_WAVES), lds_bytes, stream, p);
     } else {
-        hipLaunchKernelGGL((field_eval_kernel<false, false>), dim3(wgs), dim3(64 * MV_WAVES), lds_bytes, stream, p);
+        hipLaunchKernelGGL((field_eval_kernel<false, false, false>), dim3(wgs), dim3(64 * MV_WAVES), lds_bytes, stream, p);
     }
     return hipGetLastError();
 }

@@ -132,10 +132,20 @@ __device__ __forceinline__ void step16(const f32x4* wbuf, int ks_local, int lane
 }
 
 __device__ __forceinline__ bf16x8 relu_to_bf16(const f32x16& v, int s) {
+    // bf16(relu(x)) == relu(bf16(x)) (rounding is sign-symmetric), and on the bf16 bit pattern relu is a signed
+    // 16-bit max with 0: 4 v_cvt_pk_bf16_f32 + 4 v_pk_max_i16 per 8 values instead of 16 v_max_f32 + 4 converts
+    using i32x4 = __attribute__((ext_vector_type(4))) int;
     f32x8 t;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) t[q] = fmaxf(v[8 * s + q], 0.0f);
-    return __builtin_convertvector(t, bf16x8);
+    for (int q = 0; q < 8; ++q) t[q] = v[8 * s + q];
+    i32x4 r = __builtin_bit_cast(i32x4, __builtin_convertvector(t, bf16x8));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int w = r[q];
+        asm("v_pk_max_i16 %0, %1, 0" : "=v"(w) : "v"(w));
+        r[q] = w;
+    }
+    return __builtin_bit_cast(bf16x8, r);
 }
 
 // acc += W^T relu(in) for one hidden layer = two 16-chunk segments (input blocks 0,1 then 2,3)

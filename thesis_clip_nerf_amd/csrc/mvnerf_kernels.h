@@ -15,6 +15,7 @@ struct FieldParams {
     const float* k4;
     const float* einv;
     const float* net;      // packed (mvnerf_pack.h)
+    const float* texel_table;   // optional (B*V,H,W,128): W0_features^T features per texel, accumulator order
     float* rgbs;
     float* dir_bias;       // workspace (B*V*R,128): layer-0 accumulator seed per (view, ray)
     int32_t* tap_idx;      // optional
@@ -36,6 +37,8 @@ struct FieldParams {
 hipError_t launch_pack_net(const float* net_keras, float* packed, hipStream_t stream);
 hipError_t launch_field_eval(const FieldParams& p, hipStream_t stream);
 hipError_t launch_dir_bias(const FieldParams& p, hipStream_t stream);
+hipError_t launch_project_texels(const float* features, const float* packed_net, long n_texels, float* table,
+                                 hipStream_t stream);
 hipError_t launch_pack_net_bf16(const float* net_keras, void* packed16, hipStream_t st);
 hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hipStream_t stream);
 

@@ -85,9 +85,32 @@ def stratified_depths(u, near, far):
     return z
 
 
+def texel_table_pays(n_rays_per_scene, n_samples, h, w):
+    """Host-side rule for building a texel table for ONE field pass: the table costs H*W rows of the 256->128
+    product per view, the direct form R*S rows; the factor 2 covers the table's own launch and traffic."""
+    return n_rays_per_scene * n_samples >= 2 * h * w
+
+
+def project_texels(features, packed_net, out=None):
+    """mvnerf_project_texels: features (B,V,H,W,256), one net's packed image -> table (B,V,H,W,128)
+    (W0[123:379]^T features per texel, accumulator order) for field_eval(..., texel_table=table)."""
+    _chk(features, 'features', shape=(None, None, None, None, 256))
+    b, v, h, w, _ = features.shape
+    _chk(packed_net, 'packed_net', shape=(packed_net_floats(),))
+    if out is None:
+        out = torch.empty((b, v, h, w, 128), dtype=torch.float32, device=features.device)
+    else:
+        _chk(out, 'texel_table', shape=(b, v, h, w, 128))
+    with torch.cuda.device(features.device):
+        rc = _lib.lib().mvnerf_project_texels(_p(features), _p(packed_net), b, v, h, w, _p(out), _stream(features))
+    _lib.check(rc, 'project_texels')
+    return out
+
+
 def field_eval(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, return_taps=False,
-               return_pix=False, return_embedding=False, complete_output=False):
-    """mvnerf_field_eval: -> rgbs (B,R,S,4) [+ tap_idx (B,V,R,S,4) int32] [+ pix (B,V,R,S,2)] [+ embedding (B,R,S,128)]."""
+               return_pix=False, return_embedding=False, complete_output=False, texel_table=None):
+    """mvnerf_field_eval: -> rgbs (B,R,S,4) [+ tap_idx (B,V,R,S,4) int32] [+ pix (B,V,R,S,2)] [+ embedding (B,R,S,128)].
+    texel_table: project_texels(features, packed_net) of the SAME net -> mvnerf_field_eval_table."""
     _chk(rays_o, 'rays_o', shape=(None, None, 3))
     b, r, _ = rays_o.shape
     _chk(rays_d, 'rays_d', shape=(b, r, 3))
@@ -108,9 +131,16 @@ def field_eval(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, 
     acts_f = torch.empty((4, b, r, s, 128), dtype=torch.float32, device=dev) if complete_output else None
     ws = torch.empty(int(_lib.lib().mvnerf_field_workspace_bytes(b, v, r)), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        rc = _lib.lib().mvnerf_field_eval(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(intrinsics),
-                                          _p(extrinsics_inv), _p(packed_net), b, v, r, s, h, w, _p(rgbs), _p(taps),
-                                          _p(pix), _p(emb), _p(acts_v), _p(acts_f), _p(ws), _stream(rays_o))
+        if texel_table is None:
+            rc = _lib.lib().mvnerf_field_eval(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(intrinsics),
+                                              _p(extrinsics_inv), _p(packed_net), b, v, r, s, h, w, _p(rgbs), _p(taps),
+                                              _p(pix), _p(emb), _p(acts_v), _p(acts_f), _p(ws), _stream(rays_o))
+        else:
+            _chk(texel_table, 'texel_table', shape=(b, v, h, w, 128))
+            rc = _lib.lib().mvnerf_field_eval_table(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features),
+                                                    _p(texel_table), _p(intrinsics), _p(extrinsics_inv), _p(packed_net),
+                                                    b, v, r, s, h, w, _p(rgbs), _p(taps), _p(pix), _p(emb), _p(acts_v),
+                                                    _p(acts_f), _p(ws), _stream(rays_o))
     _lib.check(rc, 'field_eval')
     out = (rgbs,)
     if return_taps:
@@ -197,8 +227,10 @@ def render_workspace_bytes(b, v, r, s):
 
 
 def render_fwd(rays_o, rays_d, images, features, intrinsics, extrinsics_inv, packed_coarse, packed_fine, u_coarse,
-               u_fine, near, far, q7_mode=Q7_ZERO, workspace=None, out=None):
-    """mvnerf_render_fwd = MVVNeRFRenderer._call (model_v0.py:113-184) -> (rgb, depth, fine_rgb, fine_depth)."""
+               u_fine, near, far, q7_mode=Q7_ZERO, workspace=None, out=None, texel_tables=None, tables_ready=False):
+    """mvnerf_render_fwd = MVVNeRFRenderer._call (model_v0.py:113-184) -> (rgb, depth, fine_rgb, fine_depth).
+    texel_tables: None = gather raw features; 'auto' = allocate and build when texel_table_pays(); or a float32
+    tensor (2,B,V,H,W,128) [coarse net | fine net], built by this call unless tables_ready."""
     _chk(rays_o, 'rays_o', shape=(None, None, 3))
     b, r, _ = rays_o.shape
     _chk(rays_d, 'rays_d', shape=(b, r, 3))
@@ -224,11 +256,20 @@ def render_fwd(rays_o, rays_d, images, features, intrinsics, extrinsics_inv, pac
         out = (torch.empty((b, r, 3), dtype=torch.float32, device=dev), torch.empty((b, r), dtype=torch.float32, device=dev),
                torch.empty((b, r, 3), dtype=torch.float32, device=dev), torch.empty((b, r), dtype=torch.float32, device=dev))
     rgb, depth, fine_rgb, fine_depth = out
+    if isinstance(texel_tables, str):
+        if texel_tables != 'auto':
+            raise ValueError(f"texel_tables: {texel_tables!r}, expected None, 'auto' or a tensor")
+        texel_tables = (torch.empty((2, b, v, h, w, 128), dtype=torch.float32, device=dev)
+                        if texel_table_pays(r, s, h, w) else None)
+        tables_ready = False
+    if texel_tables is not None:
+        _chk(texel_tables, 'texel_tables', shape=(2, b, v, h, w, 128))
     with torch.cuda.device(dev):
         rc = _lib.lib().mvnerf_render_fwd(_p(rays_o), _p(rays_d), _p(images), _p(features), _p(intrinsics),
                                           _p(extrinsics_inv), _p(packed_coarse), _p(packed_fine), _p(u_coarse),
                                           _p(u_fine), b, v, r, s, h, w, float(near), float(far), int(q7_mode), _p(rgb),
-                                          _p(depth), _p(fine_rgb), _p(fine_depth), _p(workspace), _stream(rays_o))
+                                          _p(depth), _p(fine_rgb), _p(fine_depth), _p(workspace), _p(texel_tables),
+                                          int(bool(tables_ready)), _stream(rays_o))
     _lib.check(rc, 'render_fwd')
     return rgb, depth, fine_rgb, fine_depth
 
