@@ -55,6 +55,8 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='bf16: both field passes on the bf16 MFMA kernel (configs 3/5; not the headline)')
     ap.add_argument('--texel-table', default='auto', choices=['auto', 'on', 'off'],
                     help="f32: hoist layer 0's feature rows to a per-texel table rebuilt every step (auto: when R*S >= 2*H*W)")
+    ap.add_argument('--train-steps', type=int, default=5,
+                    help='N=1 only: also time this many train_step calls (fwd + bwd + clip + Adam) on the same scene, reported as an extra object (0 = skip)')
     ap.add_argument('--fused-call', action='store_true', help='time mvnerf_render_fwd (one C call) instead of the op sequence')
     args = ap.parse_args()
 
@@ -182,11 +184,36 @@ def main():
                     result['roofline']['traffic'] = json.load(open(pmc)).get('field_eval_fine_hbm_bytes_per_launch')
                 except Exception:
                     pass
+        if world == 1 and args.train_steps > 0 and not bf16:
+            result['train_step'] = train_throughput(sc, t, args.views, dev, args.train_steps)
         if world == 1 and args.cpu_rays > 0:
             result['cpu_baseline'], result['parity'] = cpu_baseline(sc, out, args.cpu_rays)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def train_throughput(sc, t, n_views, dev, steps):
+    """cfg2 'fwd+bwd rays/s' (SURVEY.md 8d): MVVNeRFRenderer.train_step (model_v0.py:186-197) = forward with stash,
+    full backward (incl. the gradient through the importance samples), clip-by-value, Adam; not part of `value`."""
+    from thesis_clip_nerf_amd import MVVNeRFRenderer
+    r = t['rays_o'].shape[1]
+    m = MVVNeRFRenderer(r, r, n_views=n_views, near=sc['near'], far=sc['far'], device=dev)
+    m.set_weights(sc['coarse'], sc['fine'])
+    m.compile(learning_rate=1e-4)
+    inputs = tuple(t[k] for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'])
+    y = torch.rand((1, r, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    kw = dict(combined_features=t['features'], u_coarse=t['u_coarse'], u_fine=t['u_fine'])
+    for _ in range(2):
+        m.train_step((inputs, y), **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.train_step((inputs, y), **kw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {'rays_per_sec': r / dt, 'ms_per_step': 1e3 * dt, 'steps': steps,
+            'what': 'train_step: fwd (activations stashed) + bwd of both nets incl. d/d(sample depth) + clip + Adam, fp32'}
 
 
 def cpu_baseline(sc, gpu_out, n_rays):

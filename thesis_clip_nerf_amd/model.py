@@ -66,6 +66,8 @@ class MVVNeRFRenderer:
         self._packed16 = None
         self._packed_bwd = None
         self._workspace = None
+        self._tables = None             # (2,B,V,H,W,128) texel tables [coarse | fine] of the last scene, see _call
+        self._tables_key = None
 
     # ---- weights -------------------------------------------------------------------------
     def set_weights(self, coarse_net=None, fine_net=None):
@@ -78,11 +80,13 @@ class MVVNeRFRenderer:
                 setattr(self, name, val)
         self._packed = None
         self._packed_bwd = None
+        self._tables_key = None
 
     def weights_changed(self):
         """Call after updating coarse_net / fine_net in place (e.g. an optimizer step)."""
         self._packed = None
         self._packed_bwd = None
+        self._tables_key = None
 
     def packed(self):
         if self._packed is None:
@@ -112,10 +116,14 @@ class MVVNeRFRenderer:
             u_fine = torch.rand(shape, dtype=torch.float32, device=self.device, generator=generator)
         return u_coarse, u_fine
 
-    def _call(self, inputs, n_rays, batch_size, combined_features, u_coarse=None, u_fine=None, generator=None):
+    def _call(self, inputs, n_rays, batch_size, combined_features, u_coarse=None, u_fine=None, generator=None,
+              scene_key=None):
         """model_v0.py:113-184.  inputs = (ray_origins (B,R,3), ray_directions (B,R,3),
         images (B,V,H,W,3) in [0,1], intrinsics (B,V,4,4), extrinsics_inv (B,V,4,4)).
-        Returns (rgb, depth, fine_rgb, fine_depth)."""
+        Returns (rgb, depth, fine_rgb, fine_depth).
+        The feature rows of layer 0 go through per-texel tables (include/mvnerf_hip.h, "Texel table") when that is
+        cheaper: always rebuilt for a call with R*S >= 2*H*W; with `scene_key` (any hashable naming the feature maps,
+        e.g. one frame rendered in chunks) they are built by the first call and re-used while key and weights last."""
         rays_o, rays_d, images, k4, einv = [self._dev(t) for t in inputs]
         features = self._dev(combined_features)
         if rays_o.dim() != 3 or rays_o.shape[0] != batch_size or rays_o.shape[1] != n_rays:
@@ -129,8 +137,19 @@ class MVVNeRFRenderer:
         need = ops.render_workspace_bytes(batch_size, images.shape[1], n_rays, self.n_samples)
         if self._workspace is None or self._workspace.numel() < need:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        v, h, w = images.shape[1:4]
+        tables, ready = None, False
+        if scene_key is not None or ops.texel_table_pays(n_rays, self.n_samples, h, w):
+            shape = (2, batch_size, v, h, w, 128)
+            if self._tables is None or tuple(self._tables.shape) != shape:
+                self._tables = torch.empty(shape, dtype=torch.float32, device=self.device)
+                self._tables_key = None
+            tables = self._tables
+            ready = scene_key is not None and self._tables_key == scene_key
+            self._tables_key = scene_key
         return ops.render_fwd(rays_o, rays_d, images, features, k4, einv, pc, pf, self._dev(u_coarse), self._dev(u_fine),
-                              self.near, self.far, self.q7_mode, workspace=self._workspace)
+                              self.near, self.far, self.q7_mode, workspace=self._workspace, texel_tables=tables,
+                              tables_ready=ready)
 
     def infer(self, inputs, batched_features, **kw):
         """model_v0.py:61-63 (any ray count, not only n_rays_infer=512)."""
@@ -317,9 +336,11 @@ def render_view(model, src_colors, src_camera_configs, tgt_camera_config, combin
     chunk = n if chunk is None else int(chunk)
     rgbs = torch.empty((n, 3), dtype=torch.float32, device=dev)
     depths = torch.empty((n,), dtype=torch.float32, device=dev)
+    frame = object() if model.compute_dtype == 'f32' else None           # texel tables: built by the first chunk, then re-used
     for i in range(0, n, chunk):
         sl = slice(i, min(n, i + chunk))
-        out = model.infer((rays_o[None, sl], rays_d[None, sl], images, k4, einv), combined_features, generator=generator)
+        kw = {'scene_key': frame} if frame is not None else {}
+        out = model.infer((rays_o[None, sl], rays_d[None, sl], images, k4, einv), combined_features, generator=generator, **kw)
         rgbs[sl], depths[sl] = out[2][0], out[3][0]
     rgb8, depth8 = ops.finish_view(rgbs, depths)
     return rgb8.reshape(h, w, 3).cpu().numpy(), depth8.reshape(h, w, 1).cpu().numpy()
