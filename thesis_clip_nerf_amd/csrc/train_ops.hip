@@ -119,7 +119,7 @@ hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int 
 // workgroup's tiles and adding it once at the end.
 __device__ __forceinline__ int swz_f4(int f, int chunk) { return f * 8 + (chunk ^ (f & 7)); }     // float4 index
 
-__global__ __launch_bounds__(256, 2) void dense_bwd_fused_kernel(const float* __restrict__ g_tl, const float* __restrict__ a_tl,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_bwd_fused_kernel(const float* __restrict__ g_tl, const float* __restrict__ a_tl,
                                                                  const float* __restrict__ wstream,
                                                                  const float* __restrict__ resid_tl, float* __restrict__ da_tl,
                                                                  long n_tiles, float* __restrict__ dW, float* __restrict__ db) {
@@ -135,16 +135,46 @@ __global__ __launch_bounds__(256, 2) void dense_bwd_fused_kernel(const float* __
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wstream), 0, kHiddenWFloats * 4, 0x00020000);
     const int wvoff = lane * 16 + 1024 * w;               // chunk (grp, nb = w) of every 4 KiB group
 
+    // LDS addresses as (4 lane-dependent bases) + compile-time offsets, so that they ride in the ds_read immediates
+    // instead of one address register per row (the XOR term of swz_f4 only sees the low 3 bits of the row):
+    int gbase[4], ebase[4], tbase[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        gbase[e] = swz_f4(4 * h + e, j >> 2) * 4 + (j & 3);                 // float index of G[row 4h+e (+8m)][sample j]
+        ebase[e] = swz_f4(32 * w + 4 * h + e, j >> 2) * 4 + (j & 3);        // a[row 32w + 4h + e (+8m)][sample j]
+        tbase[e] = swz_f4(i, 2 * e + h);                                    // float4 index of row i (+32m), samples 8e+4h..+3
+    }
+    // software pipeline over the workgroup's tiles: the next tile's G and a (32 KiB) are in flight, in registers,
+    // while the current one is consumed from LDS
+    f32x4 pg[4], pa[4];
+    {
+        const long t0 = blockIdx.x < n_tiles ? (long)blockIdx.x : n_tiles - 1;
+        const f32x4* gsrc = reinterpret_cast<const f32x4*>(g_tl + t0 * 4096);
+        const f32x4* asrc = reinterpret_cast<const f32x4*>(a_tl + t0 * 4096);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            pg[m] = gsrc[tid + 256 * m];
+            pa[m] = asrc[tid + 256 * m];
+        }
+    }
     for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         __syncthreads();                                   // previous tile fully consumed
-        const f32x4* gsrc = reinterpret_cast<const f32x4*>(g_tl + tile * 4096);
-        const f32x4* asrc = reinterpret_cast<const f32x4*>(a_tl + tile * 4096);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int q = tid + 256 * m;
             const int dst = swz_f4(q >> 3, q & 7);
-            sG[dst] = gsrc[q];
-            sA[dst] = asrc[q];
+            sG[dst] = pg[m];
+            sA[dst] = pa[m];
+        }
+        {
+            const long nt = tile + gridDim.x < n_tiles ? tile + gridDim.x : tile;
+            const f32x4* gsrc = reinterpret_cast<const f32x4*>(g_tl + nt * 4096);
+            const f32x4* asrc = reinterpret_cast<const f32x4*>(a_tl + nt * 4096);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                pg[m] = gsrc[tid + 256 * m];
+                pa[m] = asrc[tid + 256 * m];
+            }
         }
         __syncthreads();
         // ---- dL/da rows of block w: out[32w + i'][j] = sum_n M[n][32w + i'] G[n][j] ----
@@ -152,23 +182,32 @@ __global__ __launch_bounds__(256, 2) void dense_bwd_fused_kernel(const float* __
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         f32x4 wcur = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, 0, 0));
+        const float* sGf = reinterpret_cast<const float*>(sG);
+        float gcur[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gcur[e] = sGf[gbase[e]];
 #pragma unroll
         for (int grp = 0; grp < 16; ++grp) {
+            // operands of the next group (weights from L2, G from LDS) are requested before this group's MFMAs
             const f32x4 wnext = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, 4096 * (grp + 1), 0));
-            const int kb = grp >> 2, t = grp & 3;
+            float gnext[4];
+            const int gn = grp < 15 ? grp + 1 : grp;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n = 32 * kb + 8 * t + 4 * h + e;                       // contraction index of this k-step
-                const float gv = reinterpret_cast<const float*>(sG)[swz_f4(n, j >> 2) * 4 + (j & 3)];
-                acc = mfma(wcur[e], gv, acc);
-            }
+            for (int e = 0; e < 4; ++e)                                          // contraction index n = 32kb + 8t + 4h + e
+                gnext[e] = sGf[gbase[e] + (32 * (gn >> 2) + 8 * (gn & 3)) * 32];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma(wcur[e], gcur[e], acc);
             wcur = wnext;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gcur[e] = gnext[e];
         }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- dW rows of block w: dW[32w + i][n] += sum_j relu(a)[32w + i][j] G[n][j] ----
         f32x4 a4[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            a4[t] = sA[swz_f4(32 * w + i, 2 * t + h)];
+            a4[t] = sA[tbase[t] + 256 * w];
 #pragma unroll
             for (int e = 0; e < 4; ++e) a4[t][e] = fmaxf(a4[t][e], 0.0f);
         }
@@ -177,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void dense_bwd_fused_kernel(const float* __
             float sgsum = 0.0f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const f32x4 g4 = sG[swz_f4(32 * nb + i, 2 * t + h)];
+                const f32x4 g4 = sG[tbase[t] + 256 * nb];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     dwacc[nb] = mfma(a4[t][e], g4[e], dwacc[nb]);
@@ -185,16 +224,23 @@ __global__ __launch_bounds__(256, 2) void dense_bwd_fused_kernel(const float* __
                 }
             }
             dbacc[nb] = dbacc[nb] + sgsum;
+            __builtin_amdgcn_sched_barrier(0);             // keep one block's 16 LDS operands live at a time
         }
         // ---- epilogue of dL/da: relu mask from the staged a tile, optional residual, store ----
+        float rs[16];
+        const long obase = tl_index(tile, 128, 32 * w + 4 * h, j);           // row 32w + 4h (+ (r&3) + 8(r>>2))
+        if (resid_tl) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rs[r] = resid_tl[obase + ((r & 3) + 8 * (r >> 2)) * 32];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rs[r] = 0.0f;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int f = 32 * w + acc_row(r, h);
-            const float av = reinterpret_cast<const float*>(sA)[swz_f4(f, j >> 2) * 4 + (j & 3)];
-            const long o = tl_index(tile, 128, f, j);
-            float v = av > 0.0f ? acc[r] : 0.0f;
-            if (resid_tl) v = v + resid_tl[o];
-            da_tl[o] = v;
+            const float av = reinterpret_cast<const float*>(sA)[ebase[r & 3] + 8 * (r >> 2) * 32];
+            const float v = av > 0.0f ? acc[r] : 0.0f;
+            da_tl[obase + ((r & 3) + 8 * (r >> 2)) * 32] = resid_tl ? v + rs[r] : v;
         }
     }
     const int col = lane & 31, hh = lane >> 5;
