@@ -303,6 +303,8 @@ int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const floa
     if (V > 1 && ((long)R * S) % 32 != 0) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_stash: R*S=%ld must be a multiple of 32 when V > 1", (long)R * S);
     const long total = (long)B * R * S;
     if (total >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_stash: B*R*S too large");
+    if ((long)V * ((total + 31) / 32) >= (1L << 18))      // stash slots are addressed with 32-bit byte offsets (16 KiB per tile)
+        return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_stash: V*B*R*S/32 = %ld tiles per stash slot, at most 262143", (long)V * ((total + 31) / 32));
     if (!aligned16(features) || !aligned16(packed_net) || !aligned16(rgbs) || !aligned16(stash) || !aligned16(workspace))
         return fail(MVNERF_E_ALIGN, "mvnerf_field_eval_stash: features, packed_net, rgbs, stash, workspace must be 16-byte aligned");
     mvnerf::FieldParams p = {};

@@ -56,6 +56,10 @@ constexpr int kStageRow = 128;       // floats per staged sample row (half of th
 #ifndef MV_FMA_LERP
 #define MV_FMA_LERP 1      // feature lerps as FMAs (6 instead of 9 VALU per channel); taps/indices unaffected
 #endif
+#ifndef MV_MV_OCC
+#define MV_MV_OCC 2        // waves per SIMD the multi-view kernels are compiled for: 2 spills the view sum to
+                           // scratch (132 B/lane) and is still 5 % faster than 1 (A/B, V=3: 745k -> 786k rays/s)
+#endif
 #ifndef MV_WAVES
 #define MV_WAVES 4         // waves per workgroup of the single-view kernel (4 or 8)
 #endif
@@ -139,7 +143,7 @@ __device__ __forceinline__ int stage_offset(int row, int chunk) {      // floats
 // layer 0 is linear in the gathered features and the bilinear gather is linear in the texels, so
 // W0f^T lerp(taps) = lerp(W0f^T taps); the lerp then runs on 128 projected channels and adds into the accumulators.
 template <bool kMultiView, bool kStash, bool kProj>
-__global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, (kMultiView || kStash) ? 1 : 2) void field_eval_kernel(FieldParams p) {
+__global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? MV_MV_OCC : 2) void field_eval_kernel(FieldParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];       // 16 KiB per wave
 
     const int lane = threadIdx.x & 63;
