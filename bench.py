@@ -179,9 +179,10 @@ def main():
                 result['roofline']['reference_equiv_tflops'] = fps_ref * b * r * 2 * s / (fine_ms * 1e-3) / 1e12
                 result['roofline']['project_texels_ms_per_step'] = float(np.mean([e[4].elapsed_time(e[5]) for e in ev]))
             pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-            if os.path.exists(pmc) and not bf16 and not use_table:
+            if os.path.exists(pmc) and not bf16 and args.views == 1 and args.size == 64:   # counters were collected on cfg2
                 try:
-                    result['roofline']['traffic'] = json.load(open(pmc)).get('field_eval_fine_hbm_bytes_per_launch')
+                    key = 'field_eval_table_fine_hbm_bytes_per_launch' if use_table else 'field_eval_fine_hbm_bytes_per_launch'
+                    result['roofline']['traffic'] = json.load(open(pmc)).get(key)
                 except Exception:
                     pass
         if world == 1 and args.train_steps > 0 and not bf16:
