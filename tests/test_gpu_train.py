@@ -18,6 +18,28 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
+def test_stash_matches_complete_output():
+    """The 14 pre-activation slots the training forward leaves in HBM (tile layout [slot][tile][128][32]) against the
+    `complete_output` activations of the inference kernel: same arithmetic, so bit-identical."""
+    for views in (1, 2):
+        sc = make_scene(seed=3, n_views=views, height=16, width=16, n_rays=24, bias_scale=0.05)
+        d = {k: dev(sc[k]) for k in ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'u_coarse', 'coarse']}
+        z = ops.stratified_depths(d['u_coarse'], sc['near'], sc['far'])
+        args = (d['rays_o'], d['rays_d'], z, d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'], ops.pack_net(d['coarse']))
+        rgbs, acts = ops.field_eval(*args, complete_output=True)
+        rgbs_t, stash = ops.field_eval_stash(*args)
+        torch.cuda.synchronize()
+        assert torch.equal(rgbs, rgbs_t)
+        n = 24 * 64
+        tiles = n // 32
+        st = stash.view(torch.float32)
+        per_view = st[:7 * views * tiles * 4096].view(7, views * tiles, 128, 32)
+        fused = st[7 * views * tiles * 4096:][:7 * tiles * 4096].view(7, tiles, 128, 32)
+        for k in range(4):                       # slots 0,2,4,6 = x0..x3 per view / view mean, x4..x6 fused
+            assert torch.equal(per_view[2 * k].permute(0, 2, 1).reshape(views * n, 128), acts[k].reshape(views * n, 128)), ('view', k)
+            assert torch.equal(fused[2 * k].permute(0, 2, 1).reshape(n, 128), acts[4 + k].reshape(n, 128)), ('fused', k)
+
+
 def test_composite_bwd_matches_autograd():
     rng = np.random.default_rng(0)
     for s in (64, 128):
