@@ -235,6 +235,31 @@ int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float*
                           const float* d_rgbs, int B, int V, int R, int S, int H, int W, void* scratch, float* grad,
                           float* d_z, mvnerf_stream_t stream);
 
+/* ---- The trunk as a differentiable field on arbitrary query points. ----
+ * Reference consumer: LanguageNeRF._call (lmvnerf/model_v4.py:208-265) evaluates fine_embedding on
+ * camera_points / camera_directions derived from grasp poses and keeps outputs[4:] = (view mean, u1, u2, u3)
+ * (layers.py:376-377); its train_step (:277-322) takes d prediction / d pose inside a second tape and differentiates a
+ * loss on that gradient w.r.t. the read-out, i.e. it needs the trunk's input-gradient (VJP) and the derivative of that
+ * VJP w.r.t. its cotangent, which is the forward-mode product (JVP).  The trunk's weights are frozen there.
+ * points, dirs: (B,N,3) world space (cam point = E^-1 [p;1], cam dir = (E^-1 [d;1])[:3], Q3) - the forward value is
+ * mvnerf_field_eval(rays_o = points, rays_d = dirs, z = 0, S = 1, acts_fused = ...).
+ *
+ * mvnerf_query_jvp: tangents t_points, t_dirs (B,N,3) -> t_acts (4,B,N,128) = J [t_points; t_dirs]; acts (optional,
+ *   may be NULL) receives the primal (4,B,N,128).  workspace: mvnerf_query_workspace_bytes(B,V,N).
+ * mvnerf_query_vjp: cotangents g_acts (4,B,N,128) -> d_points, d_dirs (B,N,3) = J^T g_acts.  stash: from
+ *   mvnerf_field_eval_stash on the same inputs (R = N, S = 1, z = zeros); bwd_streams: mvnerf_pack_bwd_streams;
+ *   scratch: mvnerf_query_vjp_scratch_bytes(B,V,N), 16-byte aligned.  N % 32 == 0 when V > 1. */
+size_t mvnerf_query_workspace_bytes(int B, int V, int N);
+int mvnerf_query_jvp(const float* points, const float* dirs, const float* t_points, const float* t_dirs,
+                     const float* images, const float* features, const float* intrinsics, const float* extrinsics_inv,
+                     const float* packed_net, int B, int V, int N, int H, int W, float* acts, float* t_acts, void* workspace,
+                     mvnerf_stream_t stream);
+size_t mvnerf_query_vjp_scratch_bytes(int B, int V, int N);
+int mvnerf_query_vjp(const float* points, const float* dirs, const float* images, const float* features,
+                     const float* intrinsics, const float* extrinsics_inv, const float* bwd_streams, const float* stash,
+                     const float* g_acts, int B, int V, int N, int H, int W, void* scratch, float* d_points, float* d_dirs,
+                     mvnerf_stream_t stream);
+
 /* optimize(): clip-by-value (clip > 0) then one Adam step with the bias-corrected rate lr_t.
  * update_mask (optional): n bytes, 0 = leave the element untouched. */
 int mvnerf_adam_clip(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1, float beta2,

@@ -176,6 +176,22 @@ def field_eval(net, o, d, zs, images, features, k4, einv):
     return render_readout(net, emb)
 
 
+def query_acts(net, points, dirs, images, features, k4, einv):
+    """The trunk on arbitrary query points with `complete_output` (lmvnerf/model_v4.py:216-262: camera points and
+    directions from poses, interpolate_bilinear, fine_embedding(...)[4:]): points, dirs (B,N,3) world space ->
+    list of the 4 fused activations [view mean, u1, u2, u3], each (B,N,128).  Differentiable w.r.t. points / dirs
+    (through PE, the lerp factors) to any order autograd supports."""
+    b, v, h, w, _ = images.shape
+    n = points.shape[1]
+    world = points[:, :, None, :]                                        # (B,N,1,3): one "sample" per point
+    pix, cam = compute_pixel_in_image_mv(world, k4, einv)
+    grid = torch.cat([images * 2.0 - 1.0, features], -1).reshape(b * v, h, w, -1)
+    feat = interpolate_bilinear_xy(grid, pix.reshape(b * v, n, 2)).reshape(b * v, n, 1, -1)
+    cdir = world_to_camera_direction_vector_mv(dirs, einv)             # (B,V,N,3)
+    outs = mv_embedding(net, cam[..., :3].reshape(b * v, n, 1, 3), cdir.reshape(b * v, n, 1, 3), feat, v, complete_output=True)
+    return [o[:, :, 0] for o in outs[4:]]
+
+
 def render_call(coarse_flat, fine_flat, o, d, images, k4, einv, features, near, far, n_samples, u_coarse, u_fine,
                 stop_fine_z=False, q7_zero=True):
     """model_v0.py:113-184 -> (rgb, depth, fine_rgb, fine_depth); differentiable w.r.t. the flat nets."""

@@ -7,7 +7,7 @@ mkdir -p ../../variants
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
-     $flags -shared -o ../../variants/lib_$name.so api.hip field_eval.hip field_eval_bf16.hip ray_ops.hip unfused_ops.hip train_ops.hip &
+     $flags -shared -o ../../variants/lib_$name.so api.hip field_eval.hip field_eval_bf16.hip ray_ops.hip unfused_ops.hip train_ops.hip query_ops.hip &
 done
 wait
 ls -la ../../variants

@@ -1,0 +1,115 @@
+"""The trunk as a differentiable field on query points: forward-mode product (mvnerf_query_jvp) and
+input gradient (mvnerf_query_vjp) through the C ABI against autograd on the torch twin of the oracle in float64.
+Bars: fp32 kernels vs an fp64 reference through a positional encoding whose derivative has gain pi*2^9: the fp32
+argument of the top octave (~1e3 rad) carries ~6e-5 of absolute error, which the derivative passes on at relative
+size, so first derivatives agree to ~1e-3 relative (measured 1-3e-3; torch's own fp32 autograd is no closer);
+besides rounding, a pre-activation within ~1e-6 of zero may take the other relu branch, which moves single rows.
+Hence the two-part bar of check_close here and the tight transpose identity between the two HIP paths below."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mvnerf_torch as T
+from thesis_clip_nerf_amd import ops
+from thesis_clip_nerf_amd.synthetic import make_scene
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def make_query(seed, n_views, n_points, batch=1, hw=(16, 20)):
+    sc = make_scene(seed=seed, batch=batch, n_views=n_views, height=hw[0], width=hw[1], n_rays=n_points, bias_scale=0.05)
+    rng = np.random.default_rng(seed + 100)
+    z = rng.uniform(sc['near'], sc['far'], (batch, n_points, 1)).astype(np.float32)
+    points = (sc['rays_o'] + z * sc['rays_d']).astype(np.float32)          # points in front of the cameras
+    dirs = rng.standard_normal((batch, n_points, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    return sc, points, dirs
+
+
+def t64(a):
+    return torch.as_tensor(np.asarray(a)).to(torch.float64)
+
+
+def oracle_fn(sc):
+    net = T.unflatten_net(t64(sc['fine']))
+    geo = (t64(sc['images']), t64(sc['features']), t64(sc['intrinsics']), t64(sc['extrinsics_inv']))
+
+    def f(points, dirs):
+        return torch.stack(T.query_acts(net, points, dirs, *geo), 0)       # (4,B,N,128)
+    return f
+
+
+def rel(got, ref):
+    return float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
+
+
+def check_close(got, ref, name):
+    """Relative L2 over the tensor (3e-2: a relu flip moves a whole row) and the median per-point relative error (3e-3:
+    what rounding alone does)."""
+    rows = np.linalg.norm((got - ref).reshape(-1, ref.shape[-1]), axis=-1) / np.maximum(
+        np.linalg.norm(ref.reshape(-1, ref.shape[-1]), axis=-1), 1e-30)
+    assert rel(got, ref) < 3e-2, (name, rel(got, ref))
+    assert np.median(rows) < 3e-3, (name, float(np.median(rows)))
+
+
+@pytest.mark.parametrize('n_views,n_points,batch', [(1, 40, 1), (2, 64, 2), (3, 32, 1)])
+def test_query_jvp_matches_autograd(n_views, n_points, batch):
+    sc, points, dirs = make_query(7 + n_views, n_views, n_points, batch)
+    rng = np.random.default_rng(1)
+    tp = rng.standard_normal(points.shape).astype(np.float32) * 1e-2
+    td = rng.standard_normal(dirs.shape).astype(np.float32) * 1e-2
+    f = oracle_fn(sc)
+    acts_ref, t_ref = torch.autograd.functional.jvp(f, (t64(points), t64(dirs)), (t64(tp), t64(td)))
+    d = {k: dev(sc[k]) for k in ['images', 'features', 'intrinsics', 'extrinsics_inv', 'fine']}
+    packed = ops.pack_net(d['fine'])
+    t_acts, acts = ops.query_jvp(dev(points), dev(dirs), dev(tp), dev(td), d['images'], d['features'], d['intrinsics'],
+                                 d['extrinsics_inv'], packed, return_primal=True)
+    torch.cuda.synchronize()
+    assert np.abs(acts.cpu().numpy() - acts_ref.numpy()).max() < 2e-5 * max(1.0, float(acts_ref.abs().max()))
+    # the primal also equals the inference kernel's complete_output on the same points
+    _, acts_q = ops.query_field(dev(points), dev(dirs), d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'], packed,
+                                complete_output=True)
+    for k in range(4):
+        assert (acts[k] - acts_q[4 + k]).abs().max().item() < 2e-5 * max(1.0, acts_q[4 + k].abs().max().item())
+    got, ref = t_acts.cpu().numpy(), t_ref.numpy()
+    for k in range(4):
+        check_close(got[k], ref[k], f't_acts[{k}]')
+
+
+@pytest.mark.parametrize('n_views,n_points,batch', [(1, 40, 1), (2, 64, 2), (3, 32, 1)])
+def test_query_vjp_matches_autograd(n_views, n_points, batch):
+    sc, points, dirs = make_query(17 + n_views, n_views, n_points, batch)
+    rng = np.random.default_rng(2)
+    g = rng.standard_normal((4, batch, n_points, 128)).astype(np.float32)
+    f = oracle_fn(sc)
+    _, (dp_ref, dd_ref) = torch.autograd.functional.vjp(f, (t64(points), t64(dirs)), t64(g))
+    d = {k: dev(sc[k]) for k in ['images', 'features', 'intrinsics', 'extrinsics_inv', 'fine']}
+    geo = (d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'])
+    stash = ops.query_stash(dev(points), dev(dirs), *geo, ops.pack_net(d['fine']))
+    dp, dd = ops.query_vjp(dev(points), dev(dirs), *geo, ops.pack_bwd_streams(d['fine']), stash, dev(g))
+    torch.cuda.synchronize()
+    check_close(dp.cpu().numpy(), dp_ref.numpy(), 'd_points')
+    check_close(dd.cpu().numpy(), dd_ref.numpy(), 'd_dirs')
+
+
+def test_query_jvp_is_transpose_of_vjp():
+    """<g, J t> == <J^T g, t> for the two HIP paths themselves (fp32, same relu branches): tight bar."""
+    sc, points, dirs = make_query(31, 2, 64)
+    rng = np.random.default_rng(3)
+    tp = rng.standard_normal(points.shape).astype(np.float32)
+    td = rng.standard_normal(dirs.shape).astype(np.float32)
+    g = rng.standard_normal((4, 1, 64, 128)).astype(np.float32)
+    d = {k: dev(sc[k]) for k in ['images', 'features', 'intrinsics', 'extrinsics_inv', 'fine']}
+    geo = (d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'])
+    packed = ops.pack_net(d['fine'])
+    t_acts = ops.query_jvp(dev(points), dev(dirs), dev(tp), dev(td), *geo, packed)
+    stash = ops.query_stash(dev(points), dev(dirs), *geo, packed)
+    dp, dd = ops.query_vjp(dev(points), dev(dirs), *geo, ops.pack_bwd_streams(d['fine']), stash, dev(g))
+    lhs = float((t_acts.double() * dev(g).double()).sum())
+    rhs = float((dp.double() * dev(tp).double()).sum() + (dd.double() * dev(td).double()).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)

@@ -28,6 +28,10 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     'mvnerf_stratified_depths': (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p]),
     'mvnerf_field_eval': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p] * 8),
+    'mvnerf_query_workspace_bytes': (c_size_t, [c_int] * 3),
+    'mvnerf_query_jvp': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p] * 4),
+    'mvnerf_query_vjp_scratch_bytes': (c_size_t, [c_int] * 3),
+    'mvnerf_query_vjp': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p] * 4),
     'mvnerf_texel_table_bytes': (c_size_t, [c_int] * 4),
     'mvnerf_project_texels': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
     'mvnerf_field_eval_table': (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_void_p] * 8),

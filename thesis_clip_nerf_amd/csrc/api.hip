@@ -280,7 +280,7 @@ int mvnerf_finish_view(const float* rgb, const float* depth, long n, float* minm
 namespace {
 long tiles_for(int B, int R, int S) { return ((long)B * R * S + 31) / 32; }
 constexpr int kBwdMaxWGs = 512;      // resident workgroups of the dW kernels (2 per CU)
-constexpr int kFusedBwdWGs = 1024;   // fused dX+dW kernel: 32 KiB LDS per workgroup, 4 per CU
+constexpr int kFusedBwdWGs = 512;    // fused dX+dW kernel: 2 waves/SIMD by registers -> 2 resident workgroups per CU
 }  // namespace
 
 size_t mvnerf_stash_bytes(int B, int V, int R, int S) {
@@ -420,7 +420,95 @@ int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float*
     p.k4 = intrinsics; p.einv = extrinsics_inv;
     p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W; p.total = total; p.n_tiles = n_tiles;
     MV_TRY(launch_dw0(p, buf[g], grad + kKerasW0, grad + kKerasB0, kBwdMaxWGs, st));
-    if (d_z) MV_TRY(launch_field_dz(p, buf[g], bwd_streams + (size_t)12 * kHiddenWFloats, d_z, st));
+    if (d_z) MV_TRY(launch_field_dz(p, buf[g], bwd_streams + (size_t)12 * kHiddenWFloats, d_z, nullptr, nullptr, st));
+#undef MV_TRY
+    return 0;
+}
+
+// ---- the trunk as a differentiable field on query points --------------------------------------
+size_t mvnerf_query_workspace_bytes(int B, int V, int N) {
+    if (B <= 0 || V <= 0 || N <= 0) return 0;
+    return (size_t)2 * B * V * N * 128 * sizeof(float);        // layer-0 seed and its tangent per (view, point)
+}
+
+int mvnerf_query_jvp(const float* points, const float* dirs, const float* t_points, const float* t_dirs,
+                     const float* images, const float* features, const float* intrinsics, const float* extrinsics_inv,
+                     const float* packed_net, int B, int V, int N, int H, int W, float* acts, float* t_acts, void* workspace,
+                     mvnerf_stream_t stream) {
+    if (!points || !dirs || !t_points || !t_dirs || !images || !features || !intrinsics || !extrinsics_inv || !packed_net ||
+        !t_acts || !workspace)
+        return fail(MVNERF_E_ARG, "mvnerf_query_jvp: null pointer");
+    if (B <= 0 || V <= 0 || N <= 0) return fail(MVNERF_E_ARG, "mvnerf_query_jvp: B=%d V=%d N=%d", B, V, N);
+    if (H < 2 || W < 2) return fail(MVNERF_E_SHAPE, "mvnerf_query_jvp: source image %dx%d, need H,W >= 2", H, W);
+    if ((long)B * N >= (1L << 31) || (long)B * V * H * W >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_query_jvp: sizes too large for int32 indices");
+    if (!aligned16(features) || !aligned16(packed_net) || !aligned16(t_acts) || (acts && !aligned16(acts)) || !aligned16(workspace))
+        return fail(MVNERF_E_ALIGN, "mvnerf_query_jvp: features, packed_net, acts, t_acts, workspace must be 16-byte aligned");
+    mvnerf::FieldParams p = {};
+    p.rays_o = points; p.rays_d = dirs; p.z = nullptr; p.t_o = t_points; p.t_d = t_dirs;
+    p.images = images; p.features = features; p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net;
+    p.acts_fused = acts; p.t_acts = t_acts;
+    p.dir_bias = static_cast<float*>(workspace);
+    p.dir_tan = p.dir_bias + (size_t)B * V * N * 128;
+    p.B = B; p.V = V; p.R = N; p.S = 1; p.H = H; p.W = W;
+    p.total = (long)B * N;
+    p.n_tiles = (p.total + 31) / 32;
+    return hip_status(mvnerf::launch_field_jvp(p, static_cast<hipStream_t>(stream)), "mvnerf_query_jvp");
+}
+
+size_t mvnerf_query_vjp_scratch_bytes(int B, int V, int N) {
+    if (B <= 0 || V <= 0 || N <= 0) return 0;
+    const size_t tiles = ((size_t)B * N + 31) / 32;
+    return (size_t)3 * V * tiles * 4096 * sizeof(float);
+}
+
+int mvnerf_query_vjp(const float* points, const float* dirs, const float* images, const float* features,
+                     const float* intrinsics, const float* extrinsics_inv, const float* bwd_streams, const float* stash,
+                     const float* g_acts, int B, int V, int N, int H, int W, void* scratch, float* d_points, float* d_dirs,
+                     mvnerf_stream_t stream) {
+    using namespace mvnerf;
+    if (!points || !dirs || !images || !features || !intrinsics || !extrinsics_inv || !bwd_streams || !stash || !g_acts ||
+        !scratch || !d_points || !d_dirs)
+        return fail(MVNERF_E_ARG, "mvnerf_query_vjp: null pointer");
+    if (B <= 0 || V <= 0 || N <= 0 || H < 2 || W < 2) return fail(MVNERF_E_ARG, "mvnerf_query_vjp: bad sizes");
+    if (V > 1 && N % 32 != 0) return fail(MVNERF_E_SHAPE, "mvnerf_query_vjp: N=%d must be a multiple of 32 when V > 1", N);
+    if (!aligned16(features) || !aligned16(bwd_streams) || !aligned16(stash) || !aligned16(g_acts) || !aligned16(scratch))
+        return fail(MVNERF_E_ALIGN, "mvnerf_query_vjp: features, bwd_streams, stash, g_acts, scratch must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long total = (long)B * N, n_tiles = (total + 31) / 32, view_tiles = n_tiles * V;
+    const size_t vslot = (size_t)view_tiles * 4096, fslot = (size_t)n_tiles * 4096;
+    float* buf[3] = {static_cast<float*>(scratch), static_cast<float*>(scratch) + vslot, static_cast<float*>(scratch) + 2 * vslot};
+    auto view_slot = [&](int k) { return stash + (size_t)k * vslot; };
+    auto fused_slot = [&](int m) { return stash + 7 * vslot + (size_t)m * fslot; };
+    hipError_t e;
+#define MV_TRY(call) if ((e = (call)) != hipSuccess) return hip_status(e, "mvnerf_query_vjp")
+    MV_TRY(hipMemsetAsync(d_points, 0, (size_t)total * 3 * sizeof(float), st));
+    MV_TRY(hipMemsetAsync(d_dirs, 0, (size_t)total * 3 * sizeof(float), st));
+    // buf[g] holds dL/d(block output); the cotangents of u3, u2, u1 and the view mean enter where those tensors are produced
+    MV_TRY(launch_rows_to_tl(g_acts + (size_t)3 * total * 128, total, n_tiles, 0, buf[0], st));
+    int g = 0;
+    for (int bi = 5; bi >= 0; --bi) {
+        if (bi == 2 && V > 1) {
+            const int gn = (g + 1) % 3;
+            MV_TRY(launch_view_broadcast(buf[g], V, n_tiles / B, n_tiles, buf[gn], st));
+            g = gn;
+        }
+        const bool fused = bi >= 3;
+        const long nt = fused ? n_tiles : view_tiles;
+        const float* pre_in = fused ? fused_slot(2 * (bi - 3)) : view_slot(2 * bi);
+        const float* pre_hid = fused ? fused_slot(2 * (bi - 3) + 1) : view_slot(2 * bi + 1);
+        const int dh = (g + 1) % 3, gn = (g + 2) % 3;
+        MV_TRY(launch_dense_bwd_fused(buf[g], pre_hid, bwd_streams + (size_t)(2 * bi + 1) * kHiddenWFloats, nullptr, buf[dh], nt,
+                                      nullptr, nullptr, kFusedBwdWGs, st));
+        MV_TRY(launch_dense_bwd_fused(buf[dh], pre_in, bwd_streams + (size_t)(2 * bi) * kHiddenWFloats, buf[g], buf[gn], nt,
+                                      nullptr, nullptr, kFusedBwdWGs, st));
+        g = gn;
+        if (fused) MV_TRY(launch_rows_to_tl(g_acts + (size_t)(bi - 3) * total * 128, total, n_tiles, 1, buf[g], st));
+    }
+    FieldParams p = {};
+    p.rays_o = points; p.rays_d = dirs; p.z = nullptr; p.images = images; p.features = features;
+    p.k4 = intrinsics; p.einv = extrinsics_inv;
+    p.B = B; p.V = V; p.R = N; p.S = 1; p.H = H; p.W = W; p.total = total; p.n_tiles = n_tiles;
+    MV_TRY(launch_field_dz(p, buf[g], bwd_streams + (size_t)12 * kHiddenWFloats, nullptr, d_points, d_dirs, st));
 #undef MV_TRY
     return 0;
 }

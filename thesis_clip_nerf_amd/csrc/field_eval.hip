@@ -19,11 +19,9 @@
 namespace mvnerf {
 
 
-constexpr int kTile = 32;            // samples per wavefront (MFMA N dimension)
 // Launch shape: measured best ("Field kernel: what was measured") is the plain one: one
 // 32-sample tile per wave, 4 waves per workgroup, 2 workgroups per CU (2 waves per SIMD).  The
 // persistent / ticket-queue / raised-priority forms below are kept as build switches for A/B runs.
-constexpr int kStageRow = 128;       // floats per staged sample row (half of the 256 channels)
 
 // Tuning switches (A/B-tested on the GPU, see DESIGN.md "Field kernel: what was measured")
 #ifndef MV_PERSIST
@@ -65,34 +63,8 @@ constexpr int kStageRow = 128;       // floats per staged sample row (half of th
 #endif
 
 }  // namespace mvnerf
-#include "mvnerf_mfma.h"
+#include "mvnerf_field_common.h"
 namespace mvnerf {
-
-template <bool kAdd>
-__device__ __forceinline__ void bias_to_acc(const float* __restrict__ bperm, int h, f32x16 (&acc)[4]) {
-#if MV_ABL_BIAS
-    if (!kAdd) {
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][r] = (float)h;
-    }
-    return;
-#endif
-    const f32x4* p = reinterpret_cast<const f32x4*>(bperm + h * 64);
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = p[nb * 4 + q];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (kAdd) acc[nb][4 * q + c] = acc[nb][4 * q + c] + v[c];
-                else acc[nb][4 * q + c] = v[c];
-            }
-        }
-    }
-}
 
 // acc += W^T relu(in)   (Dense 128->128 on the pre-activated input, layers.py:285-288)
 __device__ __forceinline__ void dense128(WStream& ws, const f32x16 (&in)[4], f32x16 (&acc)[4]) {
@@ -121,22 +93,6 @@ __device__ __forceinline__ void resnet_block(WStream& ws, const float* __restric
     bias_to_acc<true>(bias1 + 128, h, x);
     dense128(ws, hid, x);
     if (kStash) store_tl(stash + slot_stride, tile, j, h, x);
-}
-
-// lane (j,h) holds features 32*nb + 8*q + 4*h + {0..3} of sample j in registers 4q..4q+3 of block nb
-__device__ __forceinline__ void store_acc(float* __restrict__ row128, int h, const f32x16 (&x)[4]) {
-    float* e = row128 + 4 * h;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 v4 = {x[nb][4 * q], x[nb][4 * q + 1], x[nb][4 * q + 2], x[nb][4 * q + 3]};
-            *reinterpret_cast<f32x4*>(e + 32 * nb + 8 * q) = v4;
-        }
-}
-
-__device__ __forceinline__ int stage_offset(int row, int chunk) {      // floats; XOR swizzle on 16-B chunks
-    return row * kStageRow + ((chunk ^ (row & 15)) << 2);
 }
 
 // kProj: the 256 feature rows of layer 0 come from the texel table (project_texels_kernel) instead of 128 k-steps:

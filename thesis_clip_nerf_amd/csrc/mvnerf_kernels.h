@@ -32,6 +32,11 @@ struct FieldParams {
     long total;            // B*R*S samples
     long n_tiles;          // ceil(total / 32)
     unsigned int* tile_counter;   // set by launch_field_eval
+    // forward-mode tangent kernel (query_ops.hip)
+    const float* t_o;      // (B,R,3) tangent of rays_o
+    const float* t_d;      // (B,R,3) tangent of rays_d
+    float* t_acts;         // (4,B,R,S,128) tangents of the view mean and the 3 fusion blocks
+    float* dir_tan;        // workspace (B*V*R,128): tangent of the layer-0 seed
 };
 
 hipError_t launch_pack_net(const float* net_keras, float* packed, hipStream_t stream);
@@ -39,6 +44,7 @@ hipError_t launch_field_eval(const FieldParams& p, hipStream_t stream);
 hipError_t launch_dir_bias(const FieldParams& p, hipStream_t stream);
 hipError_t launch_project_texels(const float* features, const float* packed_net, long n_texels, float* table,
                                  hipStream_t stream);
+hipError_t launch_field_jvp(const FieldParams& p, hipStream_t stream);
 hipError_t launch_pack_net_bf16(const float* net_keras, void* packed16, hipStream_t st);
 hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hipStream_t stream);
 
@@ -70,7 +76,9 @@ hipError_t launch_finish_view(const float* rgb, const float* depth, long n, floa
 
 // train_ops.hip
 hipError_t launch_pack_dense(const float* src, int transpose, int valid_rows, float* dst, hipStream_t st);
-hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, hipStream_t st);
+hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, float* d_o,
+                           float* d_d, hipStream_t st);
+hipError_t launch_rows_to_tl(const float* rows, long n_rows, long n_tiles, int accumulate, float* out_tl, hipStream_t st);
 hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int g_feats, long n_tiles, float* dW, int ldn,
                           int n_valid, float* db, int max_wgs, hipStream_t st);
 hipError_t launch_dense_bwd_fused(const float* g_tl, const float* a_tl, const float* wstream, const float* resid_tl,

@@ -119,6 +119,7 @@ hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int 
 // workgroup's tiles and adding it once at the end.
 __device__ __forceinline__ int swz_f4(int f, int chunk) { return f * 8 + (chunk ^ (f & 7)); }     // float4 index
 
+template <bool kDW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_bwd_fused_kernel(const float* __restrict__ g_tl, const float* __restrict__ a_tl,
                                                                  const float* __restrict__ wstream,
                                                                  const float* __restrict__ resid_tl, float* __restrict__ da_tl,
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- dW rows of block w: dW[32w + i][n] += sum_j relu(a)[32w + i][j] G[n][j] ----
+        if (kDW) {
         f32x4 a4[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             dbacc[nb] = dbacc[nb] + sgsum;
             __builtin_amdgcn_sched_barrier(0);             // keep one block's 16 LDS operands live at a time
         }
+        }
         // ---- epilogue of dL/da: relu mask from the staged a tile, optional residual, store ----
         float rs[16];
         const long obase = tl_index(tile, 128, 32 * w + 4 * h, j);           // row 32w + 4h (+ (r&3) + 8(r>>2))
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             da_tl[obase + ((r & 3) + 8 * (r >> 2)) * 32] = resid_tl ? v + rs[r] : v;
         }
     }
+    if (!kDW) return;                                      // frozen trunk (query_vjp): only dL/da is wanted
     const int col = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
@@ -258,7 +262,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 hipError_t launch_dense_bwd_fused(const float* g_tl, const float* a_tl, const float* wstream, const float* resid_tl,
                                   float* da_tl, long n_tiles, float* dW, float* db, int max_wgs, hipStream_t st) {
     const unsigned wgs = (unsigned)(n_tiles < max_wgs ? n_tiles : max_wgs);
-    hipLaunchKernelGGL(dense_bwd_fused_kernel, dim3(wgs), dim3(256), 0, st, g_tl, a_tl, wstream, resid_tl, da_tl, n_tiles, dW, db);
+    if (dW) hipLaunchKernelGGL(dense_bwd_fused_kernel<true>, dim3(wgs), dim3(256), 0, st, g_tl, a_tl, wstream, resid_tl, da_tl, n_tiles, dW, db);
+    else hipLaunchKernelGGL(dense_bwd_fused_kernel<false>, dim3(wgs), dim3(256), 0, st, g_tl, a_tl, wstream, resid_tl, da_tl, n_tiles, dW, db);
     return hipGetLastError();
 }
 
@@ -529,6 +534,24 @@ hipError_t launch_readout_bwd(const float* x_tl, const float* rgbs, const float*
     return hipGetLastError();
 }
 
+// ---- (rows,128) row-major -> tile layout, optionally added to what is there (gradient injections of query_vjp) ----
+__global__ __launch_bounds__(256) void rows_to_tl_kernel(const float* __restrict__ rows, long n_rows, long n_tiles, int accumulate,
+                                                         float* __restrict__ out_tl) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (tile, feature, sample)
+    if (i >= n_tiles * 4096) return;
+    const long tile = i >> 12;
+    const int f = (int)(i >> 5) & 127, j = (int)i & 31;
+    const long row = tile * 32 + j;
+    const float v = row < n_rows ? rows[row * 128 + f] : 0.0f;
+    out_tl[i] = accumulate ? out_tl[i] + v : v;
+}
+
+hipError_t launch_rows_to_tl(const float* rows, long n_rows, long n_tiles, int accumulate, float* out_tl, hipStream_t st) {
+    hipLaunchKernelGGL(rows_to_tl_kernel, dim3((unsigned)((n_tiles * 4096 + 255) / 256)), dim3(256), 0, st, rows, n_rows, n_tiles,
+                       accumulate, out_tl);
+    return hipGetLastError();
+}
+
 // Row r of the (B*V*R*S)-row per-view tensors -> batch-view index, global ray, global sample index.
 struct ViewRow {
     int bv, b, ray;
@@ -688,8 +711,11 @@ hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, floa
 // image [sample][channel] and are reduced in "lane = channel" form so that the four taps are coalesced reads.
 constexpr int kDfeRow = 257;       // floats per sample row of the LDS image (odd: conflict-free scatter)
 
+// Query mode (d_o / d_d given): the same chain ends in dL/d(ray origin) and dL/d(ray direction) per ray
+// instead of dL/dz - the PE(cam dir) rows 60..119 then count too (cam dir = E^-1 [d; 1], Q3).
 __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const float* __restrict__ g0_tl,
-                                                          const float* __restrict__ w0t_streams, float* __restrict__ d_z) {
+                                                          const float* __restrict__ w0t_streams, float* __restrict__ d_z,
+                                                          float* __restrict__ d_o, float* __restrict__ d_d) {
     extern __shared__ __attribute__((aligned(16))) float lds_dz[];
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -705,12 +731,14 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
     const int ray = vr.ray, b = vr.bv;                      // `b` indexes the (B*V) cameras / grids below
     const float* E = p.einv + 16 * b;
     const float* K = p.k4 + 16 * b;
-    const float zz = p.z[g];
+    const float zz = p.z ? p.z[g] : 0.0f;
     const float dx = p.rays_d[3 * ray], dy = p.rays_d[3 * ray + 1], dz = p.rays_d[3 * ray + 2];
     const float wx = p.rays_o[3 * ray] + zz * dx, wy = p.rays_o[3 * ray + 1] + zz * dy, wz = p.rays_o[3 * ray + 2] + zz * dz;
-    float cam[4];
+    float cam[4], cdir[3];
 #pragma unroll
     for (int r = 0; r < 4; ++r) cam[r] = row_dot4(E, r, wx, wy, wz, 1.0f);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cdir[r] = row_dot4(E, r, dx, dy, dz, 1.0f);
     const float q0 = row_dot4(K, 0, cam[0], cam[1], cam[2], cam[3]);
     const float q1 = row_dot4(K, 1, cam[0], cam[1], cam[2], cam[3]);
     const float q2 = row_dot4(K, 2, cam[0], cam[1], cam[2], cam[3]);
@@ -728,7 +756,7 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
 #pragma unroll
         for (int r = 0; r < 16; ++r) bin[kb][r] = g0_tl[tl_index(tile, 128, 32 * kb + acc_row(r, h), j)];
 
-    float dcam[3] = {0.0f, 0.0f, 0.0f};
+    float dcam[3] = {0.0f, 0.0f, 0.0f}, dcdir[3] = {0.0f, 0.0f, 0.0f};
     float dax = 0.0f, day = 0.0f;
 #pragma unroll 1
     for (int slab = 0; slab < 3; ++slab) {
@@ -765,6 +793,17 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
                         if (d == 0) dcam[0] += contrib;
                         else if (d == 1) dcam[1] += contrib;
                         else dcam[2] += contrib;
+                    }
+                } else if (slab == 0 && row < 120) {
+                    if (d_d && (r & 1) == 0) {                  // PE(cam dir) rows, same pairing
+                        const int d = (row - 60) / 20, oct = ((row - 60) % 20) >> 1;
+                        const float f = 3.14159274101257324f * (float)(1 << oct);
+                        float sv, cv;
+                        sincos_f32(cdir[d] * f, &sv, &cv);
+                        const float contrib = f * (v * cv - acc[nb][r + 1] * sv);
+                        if (d == 0) dcdir[0] += contrib;
+                        else if (d == 1) dcdir[1] += contrib;
+                        else dcdir[2] += contrib;
                     }
                 } else if (row >= 120 && row < 123) {
                     // rgb rows: taps of this lane's own sample (scalar loads)
@@ -829,14 +868,21 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
     float dzv = 0.0f;
     const float dirv[3] = {dx, dy, dz};
 #pragma unroll
+    for (int c = 0; c < 3; ++c) dcdir[c] += __shfl_xor(dcdir[c], 32);
+#pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float dworld = E[a] * dc[0] + E[4 + a] * dc[1] + E[8 + a] * dc[2] + E[12 + a] * dc[3];
         dzv += dworld * dirv[a];
+        if (d_o && valid && h == 0) {                       // the samples of a ray and its V views add up
+            atomicAdd(d_o + 3 * ray + a, dworld);
+            atomicAdd(d_d + 3 * ray + a, zz * dworld + (E[a] * dcdir[0] + E[4 + a] * dcdir[1] + E[8 + a] * dcdir[2]));
+        }
     }
-    if (valid && h == 0) atomicAdd(d_z + g, dzv);           // the V views of a sample add up
+    if (d_z && valid && h == 0) atomicAdd(d_z + g, dzv);    // the V views of a sample add up
 }
 
-hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, hipStream_t st) {
+hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, float* d_o,
+                           float* d_d, hipStream_t st) {
     const size_t lds_bytes = (size_t)4 * (32 * kDfeRow + 64) * sizeof(float);
     static bool attr_done[16] = {};
     int dev = 0;
@@ -848,7 +894,7 @@ hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL(field_dz_kernel, dim3((unsigned)((p.n_tiles * p.V + 3) / 4)), dim3(256), lds_bytes, st, p, g0_tl, w0t_streams, d_z);
+    hipLaunchKernelGGL(field_dz_kernel, dim3((unsigned)((p.n_tiles * p.V + 3) / 4)), dim3(256), lds_bytes, st, p, g0_tl, w0t_streams, d_z, d_o, d_d);
     return hipGetLastError();
 }
 

@@ -560,3 +560,61 @@ def render_fwd_bf16(rays_o, rays_d, images, features, intrinsics, extrinsics_inv
     rgbs_f = field_eval_bf16(rays_o, rays_d, z_all, *geo, packed_fine, packed16_fine)
     fine_rgb, fine_depth, _ = composite(z_all, rgbs_f, return_weights=False)
     return rgb, depth, fine_rgb, fine_depth
+
+
+# ---- the trunk as a differentiable field on query points (lmvnerf/model_v4.py:208-265) -------------
+def _query_shapes(points, dirs, images, features, intrinsics, extrinsics_inv):
+    _chk(points, 'points', shape=(None, None, 3))
+    b, n, _ = points.shape
+    _chk(dirs, 'dirs', shape=(b, n, 3))
+    _chk(images, 'images', shape=(b, None, None, None, 3))
+    _, v, h, w, _ = images.shape
+    _chk(features, 'features', shape=(b, v, h, w, 256))
+    _chk(intrinsics, 'intrinsics', shape=(b, v, 4, 4))
+    _chk(extrinsics_inv, 'extrinsics_inv', shape=(b, v, 4, 4))
+    return b, v, n, h, w
+
+
+def query_jvp(points, dirs, t_points, t_dirs, images, features, intrinsics, extrinsics_inv, packed_net, return_primal=False):
+    """mvnerf_query_jvp: tangents (B,N,3) of the query points / directions -> tangents (4,B,N,128) of the four fused
+    activations (view mean, u1, u2, u3) [+ the activations themselves]."""
+    b, v, n, h, w = _query_shapes(points, dirs, images, features, intrinsics, extrinsics_inv)
+    _chk(t_points, 't_points', shape=(b, n, 3))
+    _chk(t_dirs, 't_dirs', shape=(b, n, 3))
+    _chk(packed_net, 'packed_net', shape=(packed_net_floats(),))
+    dev = points.device
+    t_acts = torch.empty((4, b, n, 128), dtype=torch.float32, device=dev)
+    acts = torch.empty((4, b, n, 128), dtype=torch.float32, device=dev) if return_primal else None
+    ws = torch.empty(int(_lib.lib().mvnerf_query_workspace_bytes(b, v, n)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().mvnerf_query_jvp(_p(points), _p(dirs), _p(t_points), _p(t_dirs), _p(images), _p(features), _p(intrinsics),
+                                         _p(extrinsics_inv), _p(packed_net), b, v, n, h, w, _p(acts), _p(t_acts), _p(ws),
+                                         _stream(points))
+    _lib.check(rc, 'query_jvp')
+    return (t_acts, acts) if return_primal else t_acts
+
+
+def query_stash(points, dirs, images, features, intrinsics, extrinsics_inv, packed_net, stash=None):
+    """Forward of the trunk on query points with the pre-activations kept for query_vjp (field_eval_stash, S = 1, z = 0)."""
+    z = torch.zeros(tuple(points.shape[:2]) + (1,), dtype=torch.float32, device=points.device)
+    return field_eval_stash(points, dirs, z, images, features, intrinsics, extrinsics_inv, packed_net, stash)[1]
+
+
+def query_vjp(points, dirs, images, features, intrinsics, extrinsics_inv, bwd_streams, stash, g_acts):
+    """mvnerf_query_vjp: cotangents (4,B,N,128) of the four fused activations -> (d_points, d_dirs), each (B,N,3)."""
+    b, v, n, h, w = _query_shapes(points, dirs, images, features, intrinsics, extrinsics_inv)
+    _chk(g_acts, 'g_acts', shape=(4, b, n, 128))
+    _chk(bwd_streams, 'bwd_streams', shape=(15 * 16384,))
+    _chk(stash, 'stash', dtype=torch.uint8)
+    if stash.numel() < stash_bytes(b, v, n, 1):
+        raise ValueError(f'stash: {stash.numel()} bytes, need {stash_bytes(b, v, n, 1)}')
+    dev = points.device
+    d_points = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
+    d_dirs = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
+    scratch = torch.empty(int(_lib.lib().mvnerf_query_vjp_scratch_bytes(b, v, n)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().mvnerf_query_vjp(_p(points), _p(dirs), _p(images), _p(features), _p(intrinsics), _p(extrinsics_inv),
+                                         _p(bwd_streams), _p(stash), _p(g_acts), b, v, n, h, w, _p(scratch), _p(d_points),
+                                         _p(d_dirs), _stream(points))
+    _lib.check(rc, 'query_vjp')
+    return d_points, d_dirs
