@@ -113,3 +113,82 @@ def test_query_jvp_is_transpose_of_vjp():
     lhs = float((t_acts.double() * dev(g).double()).sum())
     rhs = float((dp.double() * dev(tp).double()).sum() + (dd.double() * dev(td).double()).sum())
     assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+
+
+# ---- LanguageNeRF train step on the HIP trunk vs the float64 restatement (oracle/lmvnerf_torch.py) ----------------
+def _language_case(seed, n_views, batch, n_points, representation):
+    from thesis_clip_nerf_amd.lmvnerf import LanguageNeRF
+    sc = make_scene(seed=seed, batch=batch, n_views=n_views, height=16, width=20, n_rays=4, bias_scale=0.05)
+    rng = np.random.default_rng(seed)
+    rot_dim = 4 if representation == 'quaternion' else 6
+
+    def poses():
+        t = (np.array([0.0, 0.0, 0.8]) + 0.1 * rng.standard_normal((batch, n_points, 3))).astype(np.float32)
+        r = rng.standard_normal((batch, n_points, rot_dim)).astype(np.float32)
+        if representation == 'quaternion':
+            r /= np.linalg.norm(r, axis=-1, keepdims=True)
+        return t, r
+    t1, r1 = poses()
+    t2, r2 = poses()
+    lab0 = rng.random((batch, n_points)).astype(np.float32)
+    lab0 /= lab0.sum(-1, keepdims=True)
+    labels = (lab0, rng.standard_normal((batch, n_points, 3)).astype(np.float32),
+              rng.standard_normal((batch, n_points, rot_dim)).astype(np.float32))
+    inputs = (t1, r1, t2, r2, sc['images'], sc['intrinsics'], sc['extrinsics_inv'])
+    torch.manual_seed(seed)
+    model = LanguageNeRF(sc['fine'], n_points_train=n_points, n_views=n_views, batch_size=batch,
+                         rotation_representation=representation, softmax_before_loss=True, device=DEV)
+    return sc, inputs, labels, model
+
+
+@pytest.mark.parametrize('n_views,batch,representation', [(1, 1, '6d'), (2, 2, 'quaternion')])
+def test_language_train_step_matches_restatement(n_views, batch, representation):
+    from oracle import lmvnerf_torch as L
+    from tests.test_oracle_lmvnerf import keras_weights
+    n_points = 3
+    sc, inputs, labels, model = _language_case(50 + n_views, n_views, batch, n_points, representation)
+    out, pred = model.loss_and_grads((inputs, labels), sc['features'])
+    torch.cuda.synchronize()
+    # float64 restatement with the same read-out weights
+    w = {k: v.detach().double().cpu().clone().requires_grad_(True) for k, v in keras_weights(model.grasp_readout).items()}
+    net = T.unflatten_net(t64(sc['fine']))
+    checks = torch.as_tensor(L.transforms_to_check(7))
+    loss, landscape, loss_t, loss_r, pred_ref = L.train_losses(w, net, [t64(a) for a in inputs], [t64(a) for a in labels], checks,
+                                                               n_points, t64(sc['features']), representation)
+    loss.sum().backward()
+    assert np.abs(pred.cpu().numpy() - pred_ref.detach().numpy()).max() < 1e-4 * max(1.0, float(pred_ref.detach().abs().max()))
+    assert abs(float(out['landscape_loss']) - float(landscape.detach().mean())) < 1e-4 * max(1.0, abs(float(landscape.detach().mean())))
+    # the two gradient losses are cosine similarities of d prediction / d pose: first derivatives through the PE (see the
+    # module docstring for the 1e-3-level fp32 error of those)
+    assert abs(float(out['grad_loss_t']) - float(loss_t.detach())) < 5e-3
+    assert abs(float(out['grad_loss_r']) - float(loss_r.detach())) < 5e-3
+    worst = 0.0
+    for k, ref in w.items():                  # oracle name -> module parameter (Keras kernels are the transposed weights)
+        if k.startswith('ds'):
+            lin = model.grasp_readout.activation_downscale[int(k[2])]
+        elif k.startswith('comb'):
+            lin = model.grasp_readout.combined_activation_downscale
+        elif k.startswith('out'):
+            lin = model.grasp_readout.output_layer
+        else:
+            blk = model.grasp_readout.block_0 if k.startswith('b0') else model.grasp_readout.block_1
+            lin = {'l0': blk.layer_0, 'l1': blk.layer_1, 'sc': blk.shortcut}[k.split('.')[1]]
+        g = (lin.weight.grad.T if k.endswith('.k') else lin.bias.grad).double().cpu().numpy()
+        r = ref.grad.numpy()
+        # (the output bias has an exactly zero gradient - softmax and d/d pose are blind to it - hence the absolute term)
+        e = np.linalg.norm(g - r)
+        worst = max(worst, e)
+        assert e < 3e-2 * np.linalg.norm(r) + 1e-6, (k, e, np.linalg.norm(r))
+    assert worst > 0.0
+
+
+def test_language_train_step_updates_readout_only():
+    sc, inputs, labels, model = _language_case(60, 1, 1, 2, '6d')
+    before = [p.detach().clone() for p in model.grasp_readout.parameters()]
+    trunk_before = model.trunk_net.clone()
+    out = model.train_step((inputs, labels), sc['features'])
+    assert all(np.isfinite(float(v)) for v in out.values())
+    assert any((a != b).any().item() for a, b in zip(before, model.grasp_readout.parameters()))
+    assert torch.equal(trunk_before, model.trunk_net)
+    scores = model.infer(inputs, model.compute_matrices().detach(), 2, sc['features'])
+    assert scores.shape == (1, 2)

@@ -1,0 +1,300 @@
+"""`LanguageNeRF` on the HIP trunk (reference: src/lib/lmvnerf/model_v4.py).
+
+The reference's language/grasp model re-uses the NeRF trunk (`fine_embedding`, frozen) as a feature field on points
+derived from grasp poses, puts a small `GraspReadout` MLP on its four fused activations and trains ONLY that read-out
+with a loss on the prediction and a loss on d prediction / d pose (nested GradientTape, model_v4.py:277-322).  Here:
+
+* the trunk is `TrunkField`: forward = `mvnerf_field_eval_stash` on the query points (activations read back from the
+  stash), backward = `mvnerf_query_vjp`, and the backward of THAT backward w.r.t. its cotangent = `mvnerf_query_jvp`
+  (the trunk is linear in nothing but the cotangent, so the double-backward the second tape needs is a JVP);
+* `GraspReadout`, the pose algebra and the losses are ordinary torch (small, and torch's autograd supplies their
+  double-backward); the CLIP / ViT / conv encoders are outside the hot path: `combined_features` is an input.
+
+Names and argument meaning follow the reference (`_call`, `compute_matrices`, `set_pose`, `train_step`, `infer`).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+
+N_FUSED = 4
+
+
+# ---- the trunk as an autograd function ----------------------------------------------------------------------
+class TrunkState:
+    """Everything the trunk needs besides the query points: source views, cameras, packed weights."""
+
+    def __init__(self, images, features, intrinsics, extrinsics_inv, net_keras):
+        self.geo = (images.contiguous(), features.contiguous(), intrinsics.contiguous(), extrinsics_inv.contiguous())
+        self.packed = ops.pack_net(net_keras)
+        self.bwd_streams = ops.pack_bwd_streams(net_keras)
+        self.n_views = images.shape[1]
+
+
+def _pad32(t, n_pad):
+    return t if n_pad == 0 else torch.cat([t, t[:, -1:].expand(-1, n_pad, -1)], 1).contiguous()
+
+
+class _TrunkVJP(torch.autograd.Function):
+    """(g_acts) -> (d_points, d_dirs) = J^T g_acts; differentiable w.r.t. g_acts: its backward is J c."""
+
+    @staticmethod
+    def forward(ctx, g_acts, points, dirs, state, stash):
+        ctx.state, ctx.points, ctx.dirs = state, points, dirs
+        return ops.query_vjp(points, dirs, *state.geo, state.bwd_streams, stash, g_acts.contiguous())
+
+    @staticmethod
+    def backward(ctx, c_points, c_dirs):
+        st = ctx.state
+        zero = torch.zeros_like(ctx.points)
+        c_points = zero if c_points is None else c_points.contiguous()
+        c_dirs = zero if c_dirs is None else c_dirs.contiguous()
+        t_acts = ops.query_jvp(ctx.points, ctx.dirs, c_points, c_dirs, *st.geo, st.packed)
+        return t_acts, None, None, None, None          # second derivatives w.r.t. the poses are not propagated
+
+
+class TrunkField(torch.autograd.Function):
+    """points, dirs (B,N,3) -> acts (4,B,N,128) = (view mean, u1, u2, u3) of the frozen trunk (layers.py:364-377)."""
+
+    @staticmethod
+    def forward(ctx, points, dirs, state):
+        b, n, _ = points.shape
+        pad = (-n) % 32 if state.n_views > 1 else 0     # the multi-view training kernels want whole 32-point tiles per scene
+        p, d = _pad32(points.detach().contiguous(), pad), _pad32(dirs.detach().contiguous(), pad)
+        stash = ops.query_stash(p, d, *state.geo, state.packed)
+        rows = b * (n + pad)
+        tiles = (rows + 31) // 32
+        fused = stash.view(torch.float32)[7 * state.n_views * tiles * 4096:][:7 * tiles * 4096].view(7, tiles, 128, 32)
+        acts = fused[0::2].permute(0, 1, 3, 2).reshape(4, tiles * 32, 128)[:, :rows].reshape(4, b, n + pad, 128)
+        ctx.state, ctx.stash, ctx.pad, ctx.n = state, stash, pad, n
+        ctx.save_for_backward(p, d)
+        return acts[:, :, :n].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_acts):
+        p, d = ctx.saved_tensors
+        if ctx.pad:
+            g_acts = torch.cat([g_acts, g_acts.new_zeros(4, g_acts.shape[1], ctx.pad, 128)], 2)
+        d_points, d_dirs = _TrunkVJP.apply(g_acts, p, d, ctx.state, ctx.stash)
+        return d_points[:, :ctx.n], d_dirs[:, :ctx.n], None
+
+
+# ---- GraspReadout (delta_ngf/layers.py:8-42) ----------------------------------------------------------------
+def _he_normal_(w):
+    fan_in = w.shape[1]
+    nn.init.trunc_normal_(w, std=math.sqrt(2.0 / fan_in) / 0.87962566103423978, a=-2 * math.sqrt(2.0 / fan_in) / 0.87962566103423978,
+                          b=2 * math.sqrt(2.0 / fan_in) / 0.87962566103423978)
+
+
+class ResNetMLPBlock(nn.Module):
+    """layers.py:262-298 with activation='elu' (the pre-activation form: act -> Dense -> act -> Dense, + shortcut)."""
+
+    def __init__(self, in_size, hidden_size, output_size, transform_shortcut=False):
+        super().__init__()
+        self.layer_0 = nn.Linear(in_size, hidden_size)
+        self.layer_1 = nn.Linear(hidden_size, output_size)
+        self.shortcut = nn.Linear(in_size, output_size, bias=False) if transform_shortcut else None
+        for lin in (self.layer_0, self.layer_1) + ((self.shortcut,) if self.shortcut is not None else ()):
+            _he_normal_(lin.weight)
+            if lin.bias is not None:
+                nn.init.zeros_(lin.bias)
+
+    def forward(self, x):
+        r = self.layer_1(nn.functional.elu(self.layer_0(nn.functional.elu(x))))
+        return (self.shortcut(x) if self.shortcut is not None else x) + r
+
+
+class GraspReadout(nn.Module):
+    def __init__(self, n_offsets, use_bias=True):
+        super().__init__()
+        self.activation_downscale = nn.ModuleList([nn.Linear(128, 64) for _ in range(N_FUSED)])
+        self.combined_activation_downscale = nn.Linear(4 * 64, 64)
+        self.block_0 = ResNetMLPBlock(n_offsets * 64, 128, 64, transform_shortcut=True)
+        self.block_1 = ResNetMLPBlock(64, 64, 64)
+        self.output_layer = nn.Linear(64, 1, bias=use_bias)
+        for lin in self.activation_downscale:
+            _he_normal_(lin.weight)
+            nn.init.zeros_(lin.bias)
+        nn.init.xavier_uniform_(self.combined_activation_downscale.weight)      # Keras default glorot_uniform
+        nn.init.zeros_(self.combined_activation_downscale.bias)
+        _he_normal_(self.output_layer.weight)
+        if self.output_layer.bias is not None:
+            nn.init.zeros_(self.output_layer.bias)
+
+    def forward(self, acts):
+        """acts: 4 x (B, np, n5, 128) -> (B, np)."""
+        ds = [nn.functional.elu(lin(a)) for lin, a in zip(self.activation_downscale, acts)]
+        x = nn.functional.elu(self.combined_activation_downscale(torch.cat(ds, -1)))
+        x = x.reshape(x.shape[0], x.shape[1], -1)                                # 'b np n5 d -> b np (n5 d)'
+        x = self.block_1(self.block_0(x))
+        return self.output_layer(torch.relu(x))[..., 0]
+
+
+# ---- pose algebra (model_v4.py:67-101, 192-206) -------------------------------------------------------------
+def _rot_y(angle):
+    c, s = math.cos(angle), math.sin(angle)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def grasp_offsets(n_5d_poses=7):
+    """`transforms_to_check`: 6 gripper-part bases x n_5d_poses steps along the local z axis -> (6*n_5d_poses, 4, 4).
+    (Affine(rotation=[0, +-pi/2, 0]) is scipy's extrinsic 'xyz' Euler = a rotation about y.)"""
+    bx, by, bz = 0.02, 0.015, 0.0125
+    step = (bx - 0.005) / ((n_5d_poses - 1) / 2)
+
+    def affine(t, ry=0.0):
+        m = np.eye(4)
+        m[:3, :3] = _rot_y(ry)
+        m[:3, 3] = t
+        return m
+    bases = [affine([0, by, 0]), affine([0, -by, 0]), affine([-bx, by, bz], math.pi / 2), affine([bx, by, bz], -math.pi / 2),
+             affine([-bx, -by, bz], math.pi / 2), affine([bx, -by, bz], -math.pi / 2)]
+    c = int((n_5d_poses - 1) / 2)
+    steps = [affine([0.0, 0.0, i * step]) for i in range(-c, c + 1)]
+    return np.array([b @ t for b in bases for t in steps], dtype=np.float32)
+
+
+def rotation_from_quaternion(q):
+    """tensorflow_graphics rotation_matrix_3d.from_quaternion (x, y, z, w; the input is used as given, not normalised)."""
+    x, y, z, w = q.unbind(-1)
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    m = torch.stack([1 - (tyy + tzz), txy - twz, txz + twy,
+                     txy + twz, 1 - (txx + tzz), tyz - twx,
+                     txz - twy, tyz + twx, 1 - (txx + tyy)], -1)
+    return m.reshape(q.shape[:-1] + (3, 3))
+
+
+def rotation_from_6d(r6):
+    """model_v4.py:196-204: both halves normalised (not orthogonalised), third column their cross product."""
+    r1 = r6[..., :3] / r6[..., :3].norm(dim=-1, keepdim=True)
+    r2 = r6[..., 3:] / r6[..., 3:].norm(dim=-1, keepdim=True)
+    r3 = torch.linalg.cross(r1, r2)
+    return torch.stack([r1, r2, r3], -1)
+
+
+def t_m_to_h_matrix(translations, rot):
+    top = torch.cat([rot, translations[..., None]], -1)
+    last = translations.new_tensor([0.0, 0.0, 0.0, 1.0]).expand(translations.shape[:-1] + (1, 4))
+    return torch.cat([top, last], -2)
+
+
+def cosine_similarity_loss(y_true, y_pred):
+    """tf.keras.losses.CosineSimilarity(axis=-1): -mean(sum(l2n(y_true) * l2n(y_pred)))."""
+    def l2n(x):
+        return x * torch.rsqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=1e-12))
+    return -(l2n(y_true) * l2n(y_pred)).sum(-1).mean()
+
+
+def kl_divergence(y_true, y_pred):
+    """tf.keras.losses.KLDivergence(reduction=NONE): per batch element, inputs clipped to [1e-7, 1]."""
+    y_true = torch.clamp(y_true, 1e-7, 1.0)
+    y_pred = torch.clamp(y_pred, 1e-7, 1.0)
+    return (y_true * torch.log(y_true / y_pred)).sum(-1)
+
+
+class LanguageNeRF(nn.Module):
+    """model_v4.py:37-330 without the encoders: `trunk_net` is the frozen fine_embedding (+ unused read-out) in the flat
+    Keras order of MVVNeRFRenderer.fine_net; `combined_features` is passed in."""
+
+    def __init__(self, trunk_net, n_points_train=5, n_views=1, n_5d_poses=7, batch_size=1, rotation_representation='quaternion',
+                 softmax_before_loss=False, device='cuda:0'):
+        super().__init__()
+        if rotation_representation not in ('quaternion', '6d'):
+            raise ValueError('Unknown rotation representation: ' + rotation_representation)
+        self.device_ = torch.device(device)
+        self.n_views, self.n_points_train, self.batch_size = n_views, n_points_train, batch_size
+        self.rotation_representation = rotation_representation
+        self.softmax_before_loss = softmax_before_loss
+        self.register_buffer('trunk_net', torch.as_tensor(trunk_net, dtype=torch.float32).reshape(-1).clone())
+        self.register_buffer('transforms_to_check', torch.from_numpy(grasp_offsets(n_5d_poses)))      # (n5,4,4)
+        self.n_transforms_to_check = self.transforms_to_check.shape[0]
+        self.grasp_readout = GraspReadout(self.n_transforms_to_check, use_bias=True)
+        self.translations = nn.Parameter(torch.zeros(batch_size, n_points_train, 3))
+        rot_dim = 4 if rotation_representation == 'quaternion' else 6
+        self.rotations = nn.Parameter(torch.zeros(batch_size, n_points_train, rot_dim))
+        self.pose_variables = [self.translations, self.rotations]
+        self.loss = kl_divergence if softmax_before_loss else None
+        self.optimizer = None
+        self.to(self.device_)
+
+    # -- reference API --
+    def compile(self, optimizer=None, loss=None, learning_rate=1e-4):
+        self.optimizer = optimizer or torch.optim.Adam(self.grasp_readout.parameters(), lr=learning_rate, eps=1e-7)
+        if loss is not None:
+            self.loss = loss
+
+    def set_pose(self, translations, rotations):
+        with torch.no_grad():
+            self.translations.copy_(torch.as_tensor(translations, dtype=torch.float32))
+            self.rotations.copy_(torch.as_tensor(rotations, dtype=torch.float32))
+
+    def compute_matrices(self):
+        rot = (rotation_from_quaternion(self.rotations) if self.rotation_representation == 'quaternion'
+               else rotation_from_6d(self.rotations))
+        return t_m_to_h_matrix(self.translations, rot)
+
+    def trunk_state(self, inputs, batched_features):
+        """inputs[4:7] = src_images (B,V,H,W,3), src_intrinsics (B,V,4,4), src_extrinsics_inv (B,V,4,4) (model_v4.py:209-213)."""
+        dev = self.device_
+        f32 = lambda t: torch.as_tensor(t, dtype=torch.float32).to(dev)
+        return TrunkState(f32(inputs[4]), f32(batched_features), f32(inputs[5]), f32(inputs[6]), self.trunk_net)
+
+    def _call(self, inputs, transforms, n_points, batched_features, state=None):
+        """model_v4.py:211-265: poses = transforms @ offsets; points = their translations, directions = their z axes;
+        trunk -> fused activations (b, np, n5, 128) x 4 -> GraspReadout -> (B, np)."""
+        state = state or self.trunk_state(inputs, batched_features)
+        poses = transforms[:, :, None] @ self.transforms_to_check[None, None]          # (B, np, n5, 4, 4)
+        points = poses[..., :3, 3].reshape(transforms.shape[0], -1, 3)                  # query order (np, n5)
+        dirs = poses[..., :3, 2].reshape(transforms.shape[0], -1, 3)                    # R @ [0,0,1]
+        acts = TrunkField.apply(points, dirs, state)                                     # (4, B, np*n5, 128)
+        acts = acts.reshape(N_FUSED, transforms.shape[0], n_points, self.n_transforms_to_check, 128)
+        return self.grasp_readout(list(acts.unbind(0)))
+
+    def infer(self, inputs, transforms, n_points_infer, batched_features):
+        with torch.no_grad():
+            return self._call(inputs, torch.as_tensor(transforms, dtype=torch.float32).to(self.device_), n_points_infer,
+                              batched_features)
+
+    def loss_and_grads(self, data, combined_features):
+        """The body of train_step (model_v4.py:277-318) up to the optimizer: returns (dict of losses, prediction)."""
+        inputs, labels = data
+        dev = self.device_
+        lab = [torch.as_tensor(l, dtype=torch.float32).to(dev) for l in labels]
+        state = self.trunk_state(inputs, combined_features)
+        self.set_pose(inputs[0], inputs[1])
+        y_pred = self._call(inputs, self.compute_matrices(), self.n_points_train, combined_features, state)
+        if self.softmax_before_loss:
+            y_pred = torch.softmax(y_pred, -1)
+        landscape_loss = self.loss(lab[0], y_pred)
+        self.set_pose(inputs[2], inputs[3])
+        prediction = self._call(inputs, self.compute_matrices(), self.n_points_train, combined_features, state)
+        grads = torch.autograd.grad(prediction.sum(), self.pose_variables, create_graph=True)
+        loss_t = cosine_similarity_loss(lab[1], grads[0])
+        if self.rotation_representation == 'quaternion':
+            loss_r = cosine_similarity_loss(lab[2], grads[1])
+        else:
+            loss_r = cosine_similarity_loss(lab[2][..., :3], grads[1][..., :3]) + cosine_similarity_loss(lab[2][..., 3:], grads[1][..., 3:])
+        loss = loss_t + loss_r + landscape_loss
+        for prm in self.grasp_readout.parameters():
+            prm.grad = None
+        loss.sum().backward(inputs=list(self.grasp_readout.parameters()))
+        return {'landscape_loss': landscape_loss.detach().mean(), 'grad_loss_t': loss_t.detach(), 'grad_loss_r': loss_r.detach(),
+                'pred': prediction.detach().mean()}, prediction.detach()
+
+    def train_step(self, data, combined_features):
+        if self.optimizer is None:
+            self.compile()
+        out, _ = self.loss_and_grads(data, combined_features)
+        for prm in self.grasp_readout.parameters():                      # optimize(): clip-by-value 1.0, then Adam
+            if prm.grad is not None:
+                prm.grad.clamp_(-1.0, 1.0)
+        self.optimizer.step()
+        return out
