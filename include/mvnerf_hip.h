@@ -121,11 +121,13 @@ size_t mvnerf_packed_net_bf16_bytes(void);
 /* Keras-order fp32 MLP (see mvnerf_pack_net) -> bf16 MFMA operand stream.  packed16: 16-byte aligned. */
 int mvnerf_pack_net_bf16(const float* net_keras, void* packed16, mvnerf_stream_t stream);
 /* As mvnerf_field_eval, with the Dense kernels taken from packed16 (biases and the per-ray layer-0 seed still come
- * from the fp32 image packed_net).  Optional outputs: tap_idx, embedding. */
+ * from the fp32 image packed_net).  Optional outputs: tap_idx, embedding, acts_fused (4,B,R,S,128) = the view mean and
+ * the three fusion blocks (the part of complete_output that LanguageNeRF consumes, lmvnerf/model_v4.py:261). */
 int mvnerf_field_eval_bf16(const float* rays_o, const float* rays_d, const float* z, const float* images,
                            const float* features, const float* intrinsics, const float* extrinsics_inv,
                            const float* packed_net, const void* packed16, int B, int V, int R, int S, int H, int W,
-                           float* rgbs, int32_t* tap_idx, float* embedding, void* workspace, mvnerf_stream_t stream);
+                           float* rgbs, int32_t* tap_idx, float* embedding, float* acts_fused, void* workspace,
+                           mvnerf_stream_t stream);
 
 /* MVVNeRFRenderer.volumetric_render (model_v0.py:89-100) with sigma_to_alpha (nerf_utils.py:129-140).
  * z (n_rays,S); rgbs (n_rays,S,4); S in {64,128,192,256}.

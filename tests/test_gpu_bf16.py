@@ -81,3 +81,21 @@ def test_renderer_compute_dtype_bf16():
         assert float((a - b).abs().max()) < 3e-2 and not torch.equal(a, b)
     with pytest.raises(ValueError):
         MVVNeRFRenderer(64, 64, compute_dtype='fp8')
+
+
+def test_bf16_fused_acts_close_to_fp32_complete_output():
+    """cfg3 (bf16 trunk as a field): the four fused activations of the bf16 kernel against the fp32 kernel's
+    complete_output on the same query points; the last one is the embedding output of the same launch."""
+    sc = make_scene(seed=9, n_views=2, height=16, width=16, n_rays=40, bias_scale=0.05)
+    d = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(DEV) for k in ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'fine']}
+    z = torch.full((1, 40, 1), 0.8, device=DEV)
+    packed, packed16 = ops.pack_net(d['fine']), ops.pack_net_bf16(d['fine'])
+    args = (d['rays_o'], d['rays_d'], z, d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'])
+    _, emb, fused = ops.field_eval_bf16(*args, packed, packed16, return_embedding=True, return_fused_acts=True)
+    _, acts = ops.field_eval(*args, packed, complete_output=True)
+    torch.cuda.synchronize()
+    assert torch.equal(fused[3], emb)
+    for k in range(4):
+        ref = acts[4 + k]
+        err = (fused[k] - ref).abs()
+        assert err.mean().item() < 2e-2 * ref.abs().mean().item(), (k, err.mean().item(), ref.abs().mean().item())

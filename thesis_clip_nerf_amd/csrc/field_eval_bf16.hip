@@ -340,6 +340,18 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
             for (int nb = 0; nb < 4; ++nb) x[nb] = xsum[nb] / nv;
         }
 
+        // one sample row (128 floats) from the accumulators: lane (j,h) holds features 32nb + 8q + 4h + {0..3}
+        auto store_row = [&](float* base) {
+            float* e = base + 128 * g + 4 * h;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v4 = {x[nb][4 * q], x[nb][4 * q + 1], x[nb][4 * q + 2], x[nb][4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(e + 32 * nb + 8 * q) = v4;
+                }
+        };
+        if (p.acts_fused && valid) store_row(p.acts_fused);                // complete_output: the view mean
         // ---- 12 segments: fusion blocks ----
 #pragma unroll 1
         for (int bi = 3; bi < 6; ++bi) {
@@ -348,17 +360,9 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
             dense128_bf16(ring, lane, x, hid);
             bias_acc<true>(bias1 + 128, h, x);
             dense128_bf16(ring, lane, hid, x);
+            if (p.acts_fused && valid) store_row(p.acts_fused + (long)(bi - 2) * p.total * 128);
         }
-        if (p.embedding && valid) {
-            float* e = p.embedding + 128 * g + 4 * h;
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v4 = {x[nb][4 * q], x[nb][4 * q + 1], x[nb][4 * q + 2], x[nb][4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(e + 32 * nb + 8 * q) = v4;
-                }
-        }
+        if (p.embedding && valid) store_row(p.embedding);
 
         // ---- segment: read-out ----
         f32x16 o;

@@ -521,8 +521,9 @@ def pack_net_bf16(net_keras):
 
 
 def field_eval_bf16(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, packed16, return_taps=False,
-                    return_embedding=False):
-    """mvnerf_field_eval_bf16: as field_eval with the Dense layers on the bf16 MFMA path."""
+                    return_embedding=False, return_fused_acts=False):
+    """mvnerf_field_eval_bf16: as field_eval with the Dense layers on the bf16 MFMA path.
+    return_fused_acts: + (4,B,R,S,128) = view mean and the three fusion blocks (complete_output[4:])."""
     _chk(rays_o, 'rays_o', shape=(None, None, 3))
     b, r, _ = rays_o.shape
     _chk(rays_d, 'rays_d', shape=(b, r, 3))
@@ -539,13 +540,14 @@ def field_eval_bf16(rays_o, rays_d, z, images, features, intrinsics, extrinsics_
     rgbs = torch.empty((b, r, s, 4), dtype=torch.float32, device=dev)
     taps = torch.empty((b, v, r, s, 4), dtype=torch.int32, device=dev) if return_taps else None
     emb = torch.empty((b, r, s, 128), dtype=torch.float32, device=dev) if return_embedding else None
+    fused = torch.empty((4, b, r, s, 128), dtype=torch.float32, device=dev) if return_fused_acts else None
     ws = torch.empty(int(_lib.lib().mvnerf_field_workspace_bytes(b, v, r)), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = _lib.lib().mvnerf_field_eval_bf16(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(intrinsics),
                                                _p(extrinsics_inv), _p(packed_net), _p(packed16), b, v, r, s, h, w, _p(rgbs),
-                                               _p(taps), _p(emb), _p(ws), _stream(rays_o))
+                                               _p(taps), _p(emb), _p(fused), _p(ws), _stream(rays_o))
     _lib.check(rc, 'field_eval_bf16')
-    out = (rgbs,) + ((taps,) if return_taps else ()) + ((emb,) if return_embedding else ())
+    out = (rgbs,) + ((taps,) if return_taps else ()) + ((emb,) if return_embedding else ()) + ((fused,) if return_fused_acts else ())
     return out if len(out) > 1 else rgbs
 
 
