@@ -54,7 +54,7 @@ def main():
     ap.add_argument('--cpu-rays', type=int, default=512, help='rays of the bounded CPU-baseline sample (0 = skip)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='bf16: both field passes on the bf16 MFMA kernel (configs 3/5; not the headline)')
     ap.add_argument('--texel-table', default='auto', choices=['auto', 'on', 'off'],
-                    help="f32: hoist layer 0's feature rows to a per-texel table rebuilt every step (auto: when R*S >= 2*H*W)")
+                    help="hoist layer 0's feature rows to a per-texel table rebuilt every step (auto: when R*S >= 2*H*W)")
     ap.add_argument('--train-steps', type=int, default=5,
                     help='N=1 only: also time this many train_step calls (fwd + bwd + clip + Adam) on the same scene, reported as an extra object (0 = skip)')
     ap.add_argument('--fused-call', action='store_true', help='time mvnerf_render_fwd (one C call) instead of the op sequence')
@@ -95,8 +95,7 @@ def main():
     near, far = sc['near'], sc['far']
     field_args = (t['images'], t['features'], t['intrinsics'], t['extrinsics_inv'])
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
-    use_table = (not bf16) and (args.texel_table == 'on' or (args.texel_table == 'auto' and
-                                                              ops.texel_table_pays(r, s, args.size, args.size)))
+    use_table = args.texel_table == 'on' or (args.texel_table == 'auto' and ops.texel_table_pays(r, s, args.size, args.size))
     tables = torch.empty((2, b, args.views, args.size, args.size, 128), dtype=torch.float32, device=dev) if use_table else None
 
     def step_ops(e=None):
@@ -108,13 +107,13 @@ def main():
         if e: e[5].record()
         z = ops.stratified_depths(t['u_coarse'], near, far)
         if e: e[0].record()
-        rgbs_c = (ops.field_eval_bf16(t['rays_o'], t['rays_d'], z, *field_args, pc, pc16) if bf16 else
+        rgbs_c = (ops.field_eval_bf16(t['rays_o'], t['rays_d'], z, *field_args, pc, pc16, texel_table=tab_c) if bf16 else
                   ops.field_eval(t['rays_o'], t['rays_d'], z, *field_args, pc, texel_table=tab_c))
         if e: e[1].record()
         rgb, depth, w = ops.composite(z, rgbs_c)
         z_all = ops.resample(z, w, t['u_fine'])
         if e: e[2].record()
-        rgbs_f = (ops.field_eval_bf16(t['rays_o'], t['rays_d'], z_all, *field_args, pf, pf16) if bf16 else
+        rgbs_f = (ops.field_eval_bf16(t['rays_o'], t['rays_d'], z_all, *field_args, pf, pf16, texel_table=tab_f) if bf16 else
                   ops.field_eval(t['rays_o'], t['rays_d'], z_all, *field_args, pf, texel_table=tab_f))
         if e: e[3].record()
         fine_rgb, fine_depth, _ = ops.composite(z_all, rgbs_f, return_weights=False)
@@ -163,7 +162,7 @@ def main():
             achieved = flops_f / (fine_ms * 1e-3) / 1e12
             peak = 2500.0 if bf16 else PEAK_FP32_MFMA_TFLOPS          # dense bf16 MFMA peak ~2.5 PFLOP/s
             kname = (('field_eval_bf16_kernel' if bf16 else 'field_eval_kernel') + ('<true' if args.views > 1 else '<false') +
-                     ('>' if bf16 else (',false,true>' if use_table else ',false,false>')))
+                     ((',true>' if use_table else ',false>') if bf16 else (',false,true>' if use_table else ',false,false>')))
             result['roofline'] = {
                 'bound': 'mfma', 'kernel': kname + ' (fine pass, S=128)',
                 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,

@@ -122,9 +122,11 @@ size_t mvnerf_packed_net_bf16_bytes(void);
 int mvnerf_pack_net_bf16(const float* net_keras, void* packed16, mvnerf_stream_t stream);
 /* As mvnerf_field_eval, with the Dense kernels taken from packed16 (biases and the per-ray layer-0 seed still come
  * from the fp32 image packed_net).  Optional outputs: tap_idx, embedding, acts_fused (4,B,R,S,128) = the view mean and
- * the three fusion blocks (the part of complete_output that LanguageNeRF consumes, lmvnerf/model_v4.py:261). */
+ * the three fusion blocks (the part of complete_output that LanguageNeRF consumes, lmvnerf/model_v4.py:261).
+ * texel_table (optional, may be NULL): mvnerf_project_texels(features, packed_net) - the fp32 table of the same net;
+ * the feature rows of layer 0 are then an fp32 lerp of table rows instead of bf16 MFMA products. */
 int mvnerf_field_eval_bf16(const float* rays_o, const float* rays_d, const float* z, const float* images,
-                           const float* features, const float* intrinsics, const float* extrinsics_inv,
+                           const float* features, const float* texel_table, const float* intrinsics, const float* extrinsics_inv,
                            const float* packed_net, const void* packed16, int B, int V, int R, int S, int H, int W,
                            float* rgbs, int32_t* tap_idx, float* embedding, float* acts_fused, void* workspace,
                            mvnerf_stream_t stream);

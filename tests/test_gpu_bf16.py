@@ -99,3 +99,23 @@ def test_bf16_fused_acts_close_to_fp32_complete_output():
         ref = acts[4 + k]
         err = (fused[k] - ref).abs()
         assert err.mean().item() < 2e-2 * ref.abs().mean().item(), (k, err.mean().item(), ref.abs().mean().item())
+
+
+def test_bf16_texel_table_close_to_direct():
+    """bf16 kernel with layer 0's feature rows from the fp32 texel table: closer to (or as close as) the fp32 kernel than
+    the all-bf16 form, identical tap indices, and the same rendered-output bound."""
+    sc = make_scene(seed=11, n_views=2, height=24, width=24, n_rays=64, bias_scale=0.05)
+    d = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(DEV) for k in ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'fine', 'u_coarse']}
+    z = ops.stratified_depths(d['u_coarse'], sc['near'], sc['far'])
+    packed, packed16 = ops.pack_net(d['fine']), ops.pack_net_bf16(d['fine'])
+    args = (d['rays_o'], d['rays_d'], z, d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'])
+    table = ops.project_texels(d['features'], packed)
+    ref, taps_ref = ops.field_eval(*args, packed, return_taps=True)
+    direct = ops.field_eval_bf16(*args, packed, packed16)
+    tab, taps = ops.field_eval_bf16(*args, packed, packed16, return_taps=True, texel_table=table)
+    torch.cuda.synchronize()
+    assert torch.equal(taps, taps_ref)
+    e_direct = (direct - ref).abs().mean().item()
+    e_tab = (tab - ref).abs().mean().item()
+    assert e_tab < 1.2 * e_direct + 1e-6, (e_tab, e_direct)
+    assert (tab - ref).abs().max().item() < 2e-2

@@ -156,11 +156,12 @@ int mvnerf_pack_net_bf16(const float* net_keras, void* packed16, mvnerf_stream_t
 }
 
 int mvnerf_field_eval_bf16(const float* rays_o, const float* rays_d, const float* z, const float* images,
-                           const float* features, const float* intrinsics, const float* extrinsics_inv,
+                           const float* features, const float* texel_table, const float* intrinsics, const float* extrinsics_inv,
                            const float* packed_net, const void* packed16, int B, int V, int R, int S, int H, int W,
                            float* rgbs, int32_t* tap_idx, float* embedding, float* acts_fused, void* workspace,
                            mvnerf_stream_t stream) {
     if (acts_fused && !aligned16(acts_fused)) return fail(MVNERF_E_ALIGN, "mvnerf_field_eval_bf16: acts_fused must be 16-byte aligned");
+    if (texel_table && !aligned16(texel_table)) return fail(MVNERF_E_ALIGN, "mvnerf_field_eval_bf16: texel_table must be 16-byte aligned");
     if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !packed_net || !packed16 || !rgbs || !workspace)
         return fail(MVNERF_E_ARG, "mvnerf_field_eval_bf16: null pointer");
     if (B <= 0 || V <= 0 || R <= 0 || S <= 0) return fail(MVNERF_E_ARG, "mvnerf_field_eval_bf16: B=%d V=%d R=%d S=%d", B, V, R, S);
@@ -174,6 +175,7 @@ int mvnerf_field_eval_bf16(const float* rays_o, const float* rays_d, const float
     p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.images = images; p.features = features;
     p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs; p.tap_idx = tap_idx; p.embedding = embedding;
     p.acts_fused = acts_fused;
+    p.texel_table = texel_table;
     p.dir_bias = static_cast<float*>(workspace);
     p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W;
     p.total = total;

@@ -84,11 +84,14 @@ struct Ring {
     f32x4* base;        // LDS
     int c;              // ring slot of the current segment
     int p, P, V;
+    int per_view;       // segments per view: 17, or 13 when the feature rows come from the texel table
     int tid, wave;
 };
 
-__device__ __forceinline__ int ring_start_chunk(int p, int V) {
-    const int q = p < 17 * V ? p % 17 : 17 + (p - 17 * V);
+__device__ __forceinline__ int ring_start_chunk(int p, int V, int per_view) {
+    const int skip = 17 - per_view;                                  // 0, or 4 feature segments left out
+    int q = p < per_view * V ? p % per_view : per_view + (p - per_view * V);
+    if (q >= 1) q += skip;                                            // q in the 30-segment numbering of the stream
     return q < 5 ? 16 * q : (q < 29 ? kW16Hidden + 16 * (q - 5) : kW16Readout);
 }
 
@@ -96,7 +99,7 @@ __device__ __forceinline__ int ring_start_chunk(int p, int V) {
 __device__ __forceinline__ void ring_issue(const Ring& r, int ahead) {
     int pp = r.p + ahead;
     if (pp >= r.P) pp -= r.P;
-    const f32x4* src = r.w16 + (long)ring_start_chunk(pp, r.V) * 64 + r.tid;
+    const f32x4* src = r.w16 + (long)ring_start_chunk(pp, r.V, r.per_view) * 64 + r.tid;
     f32x4* dst = r.base + ((r.c + ahead) % kRing) * kSegF4 + 64 * r.wave;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -176,7 +179,11 @@ __device__ __forceinline__ void bias_acc(const float* __restrict__ bperm, int h,
 
 constexpr int kStage16Row = 256;      // bytes per staged sample row: 128 channels x bf16
 
-template <bool kMultiView>
+// kProj: layer 0's feature rows come from the fp32 texel table (field_eval.hip, project_texels_kernel): a 128-channel
+// lerp of table rows added to the accumulators replaces the four feature segments (64 MFMAs per tile) and halves the
+// gather.  All gathers run in batches of 4 iterations with their 16 loads issued up front: the 8 waves of the
+// workgroup share the weight ring, hence gather at the same time, and nothing else hides that latency.
+template <bool kMultiView, bool kProj>
 __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, const f32x4* __restrict__ w16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
     constexpr int kRingBytes = kRing * kSegF4 * 16;                       // 80 KiB
@@ -194,7 +201,8 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
     ring.c = 0;
     ring.p = 0;
     ring.V = p.V;
-    ring.P = 17 * p.V + 13;
+    ring.per_view = kProj ? 13 : 17;
+    ring.P = ring.per_view * p.V + 13;
     ring.tid = tid;
     ring.wave = wave;
     ring_issue(ring, 0);
@@ -282,29 +290,93 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
             }
             ring_next<true>(ring);
 
+            if (kProj) {
+                // ---- texel table: two passes of 64 channels (accumulator blocks nb = 2P, 2P+1 of both lane halves) ----
+                // a table row is [h][nb][16]; pass P takes floats h*64 + P*32 + {0..31}: two 128-B pieces per row.
+                // 16 lanes per sample row, 4 rows per load instruction, 4 taps, batches of 4 instructions per tap.
+                const int l16 = lane & 15, sub = lane >> 4;
+                const f32x4* tbase = reinterpret_cast<const f32x4*>(p.texel_table) + (l16 >> 3) * 16 + (l16 & 7);
+#pragma unroll
+                for (int P = 0; P < 2; ++P) {                       // unrolled: x[2P + nbl] must be a static register index
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+                    for (int it0 = 0; it0 < 8; it0 += 4) {
+                        f32x4 tv[4][4];
+                        float axs[4], ays[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int src = 4 * (it0 + u) + sub;
+                            const int tls = __shfl(tl, src);
+                            axs[u] = __shfl(tp.ax, src);
+                            ays[u] = __shfl(tp.ay, src);
+                            const f32x4* f = tbase + (long)tls * 32 + P * 8;
+                            tv[u][0] = f[0];
+                            tv[u][1] = f[32];
+                            tv[u][2] = f[(long)p.W * 32];
+                            tv[u][3] = f[(long)p.W * 32 + 32];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int src = 4 * (it0 + u) + sub;
+                            f32x4 o;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float top = fmaf(axs[u], tv[u][1][c] - tv[u][0][c], tv[u][0][c]);
+                                const float bot = fmaf(axs[u], tv[u][3][c] - tv[u][2][c], tv[u][2][c]);
+                                o[c] = fmaf(ays[u], bot - top, top);
+                            }
+                            *reinterpret_cast<f32x4*>(stage + src * kStage16Row + ((l16 ^ (src & 15)) << 4)) = o;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int nbl = 0; nbl < 2; ++nbl)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 t4 = *reinterpret_cast<const f32x4*>(stage + j * kStage16Row + (((8 * h + 4 * nbl + q) ^ (j & 15)) << 4));
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) x[2 * P + nbl][4 * q + c] += t4[c];
+                        }
+                }
+            }
             // ---- 4 segments: the two 128-channel halves of the gathered features, 4 k-steps per segment ----
 #pragma unroll 1
-            for (int hf = 0; hf < 2; ++hf) {
+            for (int hf = 0; hf < (kProj ? 0 : 2); ++hf) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const f32x4* fbase = reinterpret_cast<const f32x4*>(p.features) + hf * 32 + j;
-#pragma unroll 4
-                for (int it = 0; it < 16; ++it) {
-                    const int src = 2 * it + h;
-                    const int tls = __shfl(tl, src);
-                    const float axs = __shfl(tp.ax, src), ays = __shfl(tp.ay, src);
-                    const f32x4* f = fbase + (long)tls * 64;
-                    const f32x4 vtl = f[0], vtr = f[64], vbl = f[(long)p.W * 64], vbr = f[(long)p.W * 64 + 64];
-                    using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
-                    f32x4 o;
+                using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+#pragma unroll 1
+                for (int it0 = 0; it0 < 16; it0 += 4) {
+                    f32x4 tv[4][4];
+                    float axs[4], ays[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float top = fmaf(axs, vtr[c] - vtl[c], vtl[c]);
-                        const float bot = fmaf(axs, vbr[c] - vbl[c], vbl[c]);
-                        o[c] = fmaf(ays, bot - top, top);
+                    for (int u = 0; u < 4; ++u) {
+                        const int src = 2 * (it0 + u) + h;
+                        const int tls = __shfl(tl, src);
+                        axs[u] = __shfl(tp.ax, src);
+                        ays[u] = __shfl(tp.ay, src);
+                        const f32x4* f = fbase + (long)tls * 64;
+                        tv[u][0] = f[0];
+                        tv[u][1] = f[64];
+                        tv[u][2] = f[(long)p.W * 64];
+                        tv[u][3] = f[(long)p.W * 64 + 64];
                     }
-                    // row `src`, channels 4j..4j+3 (8 bytes); 16-byte chunks XOR-swizzled by the row
-                    const int off = src * kStage16Row + (((j >> 1) ^ (src & 15)) << 4) + ((j & 1) << 3);
-                    *reinterpret_cast<bf16x4*>(stage + off) = __builtin_convertvector(o, bf16x4);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int src = 2 * (it0 + u) + h;
+                        f32x4 o;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float top = fmaf(axs[u], tv[u][1][c] - tv[u][0][c], tv[u][0][c]);
+                            const float bot = fmaf(axs[u], tv[u][3][c] - tv[u][2][c], tv[u][2][c]);
+                            o[c] = fmaf(ays[u], bot - top, top);
+                        }
+                        // row `src`, channels 4j..4j+3 (8 bytes); 16-byte chunks XOR-swizzled by the row
+                        const int off = src * kStage16Row + (((j >> 1) ^ (src & 15)) << 4) + ((j & 1) << 3);
+                        *reinterpret_cast<bf16x4*>(stage + off) = __builtin_convertvector(o, bf16x4);
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -406,10 +478,12 @@ hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hi
             hipDeviceProp_t prop;
             if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
             cus[dev] = prop.multiProcessorCount;
-            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_eval_bf16_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess) return e;
-            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_eval_bf16_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess) return e;
+            const void* fns[4] = {reinterpret_cast<const void*>(&field_eval_bf16_kernel<false, false>),
+                                  reinterpret_cast<const void*>(&field_eval_bf16_kernel<false, true>),
+                                  reinterpret_cast<const void*>(&field_eval_bf16_kernel<true, false>),
+                                  reinterpret_cast<const void*>(&field_eval_bf16_kernel<true, true>)};
+            for (const void* fn : fns)
+                if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess) return e;
             attr_done[dev] = true;
         }
     }
@@ -417,10 +491,13 @@ hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hi
     const long n_groups = (p.n_tiles + 7) / 8;
     const unsigned wgs = (unsigned)(n_groups < cus[dev] ? n_groups : cus[dev]);
     const f32x4* w16 = static_cast<const f32x4*>(packed16);
-    if (p.V > 1)
-        hipLaunchKernelGGL(field_eval_bf16_kernel<true>, dim3(wgs), dim3(512), lds_bytes, stream, p, w16);
-    else
-        hipLaunchKernelGGL(field_eval_bf16_kernel<false>, dim3(wgs), dim3(512), lds_bytes, stream, p, w16);
+    if (p.V > 1) {
+        if (p.texel_table) hipLaunchKernelGGL((field_eval_bf16_kernel<true, true>), dim3(wgs), dim3(512), lds_bytes, stream, p, w16);
+        else hipLaunchKernelGGL((field_eval_bf16_kernel<true, false>), dim3(wgs), dim3(512), lds_bytes, stream, p, w16);
+    } else {
+        if (p.texel_table) hipLaunchKernelGGL((field_eval_bf16_kernel<false, true>), dim3(wgs), dim3(512), lds_bytes, stream, p, w16);
+        else hipLaunchKernelGGL((field_eval_bf16_kernel<false, false>), dim3(wgs), dim3(512), lds_bytes, stream, p, w16);
+    }
     return hipGetLastError();
 }
 

@@ -521,7 +521,7 @@ def pack_net_bf16(net_keras):
 
 
 def field_eval_bf16(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, packed16, return_taps=False,
-                    return_embedding=False, return_fused_acts=False):
+                    return_embedding=False, return_fused_acts=False, texel_table=None):
     """mvnerf_field_eval_bf16: as field_eval with the Dense layers on the bf16 MFMA path.
     return_fused_acts: + (4,B,R,S,128) = view mean and the three fusion blocks (complete_output[4:])."""
     _chk(rays_o, 'rays_o', shape=(None, None, 3))
@@ -541,9 +541,11 @@ def field_eval_bf16(rays_o, rays_d, z, images, features, intrinsics, extrinsics_
     taps = torch.empty((b, v, r, s, 4), dtype=torch.int32, device=dev) if return_taps else None
     emb = torch.empty((b, r, s, 128), dtype=torch.float32, device=dev) if return_embedding else None
     fused = torch.empty((4, b, r, s, 128), dtype=torch.float32, device=dev) if return_fused_acts else None
+    if texel_table is not None:
+        _chk(texel_table, 'texel_table', shape=(b, v, h, w, 128))
     ws = torch.empty(int(_lib.lib().mvnerf_field_workspace_bytes(b, v, r)), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        rc = _lib.lib().mvnerf_field_eval_bf16(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(intrinsics),
+        rc = _lib.lib().mvnerf_field_eval_bf16(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(texel_table), _p(intrinsics),
                                                _p(extrinsics_inv), _p(packed_net), _p(packed16), b, v, r, s, h, w, _p(rgbs),
                                                _p(taps), _p(emb), _p(fused), _p(ws), _stream(rays_o))
     _lib.check(rc, 'field_eval_bf16')
@@ -552,14 +554,24 @@ def field_eval_bf16(rays_o, rays_d, z, images, features, intrinsics, extrinsics_
 
 
 def render_fwd_bf16(rays_o, rays_d, images, features, intrinsics, extrinsics_inv, packed_coarse, packed_fine, packed16_coarse,
-                    packed16_fine, u_coarse, u_fine, near, far, q7_mode=Q7_ZERO):
-    """`_call` with both field passes on the bf16 path (sampling, compositing and resampling stay fp32)."""
+                    packed16_fine, u_coarse, u_fine, near, far, q7_mode=Q7_ZERO, texel_tables='auto'):
+    """`_call` with both field passes on the bf16 path (sampling, compositing and resampling stay fp32).
+    texel_tables: 'auto' (build the two fp32 tables when texel_table_pays), None, or a (2,B,V,H,W,128) tensor to fill."""
     geo = (images, features, intrinsics, extrinsics_inv)
+    tab_c = tab_f = None
+    if isinstance(texel_tables, str):
+        b, r, s = u_coarse.shape
+        h, w_ = images.shape[2:4]
+        texel_tables = (torch.empty((2,) + tuple(features.shape[:4]) + (128,), dtype=torch.float32, device=features.device)
+                        if texel_table_pays(r, s, h, w_) else None)
+    if texel_tables is not None:
+        tab_c = project_texels(features, packed_coarse, out=texel_tables[0])
+        tab_f = project_texels(features, packed_fine, out=texel_tables[1])
     z = stratified_depths(u_coarse, near, far)
-    rgbs_c = field_eval_bf16(rays_o, rays_d, z, *geo, packed_coarse, packed16_coarse)
+    rgbs_c = field_eval_bf16(rays_o, rays_d, z, *geo, packed_coarse, packed16_coarse, texel_table=tab_c)
     rgb, depth, w = composite(z, rgbs_c)
     z_all = resample(z, w, u_fine, q7_mode)
-    rgbs_f = field_eval_bf16(rays_o, rays_d, z_all, *geo, packed_fine, packed16_fine)
+    rgbs_f = field_eval_bf16(rays_o, rays_d, z_all, *geo, packed_fine, packed16_fine, texel_table=tab_f)
     fine_rgb, fine_depth, _ = composite(z_all, rgbs_f, return_weights=False)
     return rgb, depth, fine_rgb, fine_depth
 
