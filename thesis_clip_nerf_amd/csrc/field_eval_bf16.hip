@@ -2,12 +2,14 @@
 // inputs, fp32 accumulate).  Same math and interfaces as field_eval.hip; what changes is the machine mapping:
 //
 //  * v_mfma_f32_32x32x16_bf16 runs 16x faster than the fp32 MFMA, so a wave can no longer stream its own
-//    copy of the weights from L2 (that would need > 64 B/clk/CU of L1 bandwidth).  A 512-thread workgroup
-//    (8 waves = 8 tiles of 32 samples, one workgroup per CU, persistent over tile groups) shares them:
-//    the bf16 weight stream is cut into 16 KiB segments (4 k-steps x 4 output blocks) that travel through a
-//    ring of 5 LDS buffers by LDS-DMA (global_load_lds_dwordx4, no VGPR staging): while the waves run the MFMAs
-//    of segment i, the loads of segments i+1..i+3 are in flight (a segment's MFMAs last about one L2 round
-//    trip, so a distance of 1 leaves the latency exposed); one counted vmcnt + workgroup barrier per segment.
+//    copy of the weights from L2 (that would need > 64 B/clk/CU of L1 bandwidth).  A workgroup of 4 waves
+//    (4 tiles of 32 samples; two workgroups per CU, persistent over tile groups) shares them: the bf16 weight
+//    stream is cut into 8 KiB segments (2 k-steps x 4 output blocks) that travel through a ring of 5 LDS buffers
+//    by LDS-DMA (global_load_lds_dwordx4, no VGPR staging): while the waves run the MFMAs of segment i, the loads
+//    of segments i+1..i+3 are in flight; one counted vmcnt + workgroup barrier per segment.  The waves of a
+//    workgroup are in lock-step (they share the ring), so their gather / sin-cos phases leave the matrix pipe
+//    idle; the second, independent workgroup on the CU fills those holes (MV16_WAVES=8 is the single 512-thread
+//    workgroup form: half the weight traffic, no such overlap).
 //  * activations stay fp32 in the accumulators (residual path, biases, read-out in fp32) and are rounded to
 //    bf16 only when a register block is fed as the next MFMA's B operand (v_cvt_pk_bf16_f32); gathered
 //    features are lerped in fp32, rounded once, and transposed through a wave-private bf16 LDS image.
@@ -74,37 +76,64 @@ hipError_t launch_pack_net_bf16(const float* net_keras, void* packed16, hipStrea
 }
 
 // ---- the segment ring ----------------------------------------------------------------------------------------
-// Per tile the waves consume, for every view, segments q = 0..16 (layer 0: PE+rgb, 4 quarter passes of the
-// features; 3 per-view blocks = 12 half layers) and then q = 17..29 (3 fusion blocks, read-out).  Position p in
-// [0, P = 17V + 13) -> q -> first chunk.  The weights are the same for every tile, so positions wrap modulo P.
-constexpr int kRing = 5, kAhead = 3, kSegF4 = 1024;            // 5 x 16 KiB; float4 per segment
+// A workgroup of kWgWaves waves shares the weight stream through a ring of kRing LDS slots of kSegChunks chunks
+// (kKs k-steps x 4 output blocks), filled by LDS-DMA, 2 wave-instructions (2 KiB) per wave and segment.
+// Per tile the waves consume, for every view, the layer-0 segments (PE + rgb; the feature rows unless they come from
+// the texel table) and the 3 per-view blocks, then the 3 fusion blocks and the read-out.  Position p in [0, P) ->
+// first chunk of the segment.  The weights are the same for every tile, so positions wrap modulo P.
+#ifndef MV16_WAVES
+#define MV16_WAVES 8       // 4: two independent 256-thread workgroups per CU (their gather / VALU phases overlap the
+#endif                     //    other's MFMA phases); 8: one 512-thread workgroup per CU (half the weight traffic)
+#ifndef MV16_PIPE_A
+#define MV16_PIPE_A 1      // A operands of k-step ks+1 requested before the MFMAs of ks (0: compiler-scheduled)
+#endif
+#ifndef MV16_ABL_DMA
+#define MV16_ABL_DMA 0     // timing-only ablations (wrong results): no weight DMA after the prologue
+#endif
+#ifndef MV16_ABL_GATHER
+#define MV16_ABL_GATHER 0  // no table / feature gather
+#endif
+#ifndef MV16_ABL_PE
+#define MV16_ABL_PE 0      // no sin/cos
+#endif
+#ifndef MV16_ABL_BARRIER
+#define MV16_ABL_BARRIER 0 // no workgroup barrier at segment ends
+#endif
+constexpr int kWgWaves = MV16_WAVES;
+constexpr int kSegChunks = 2 * kWgWaves;                       // 16 or 8 chunks of 1 KiB
+constexpr int kKs = kSegChunks / 4;                            // k-steps (of 16 rows) per segment: 4 or 2
+constexpr int kRing = 5, kAhead = 3, kSegF4 = kSegChunks * 64;  // float4 per slot
+constexpr int kHiddenUnits = 192 / kSegChunks;                 // segments of 3 blocks (6 Dense layers x 32 chunks)
 
 struct Ring {
     const f32x4* w16;
     f32x4* base;        // LDS
     int c;              // ring slot of the current segment
     int p, P, V;
-    int per_view;       // segments per view: 17, or 13 when the feature rows come from the texel table
+    int l0_units;       // layer-0 segments per view: PE + rgb only (texel table) or PE + rgb + 256 feature rows
     int tid, wave;
 };
 
-__device__ __forceinline__ int ring_start_chunk(int p, int V, int per_view) {
-    const int skip = 17 - per_view;                                  // 0, or 4 feature segments left out
-    int q = p < per_view * V ? p % per_view : per_view + (p - per_view * V);
-    if (q >= 1) q += skip;                                            // q in the 30-segment numbering of the stream
-    return q < 5 ? 16 * q : (q < 29 ? kW16Hidden + 16 * (q - 5) : kW16Readout);
+__device__ __forceinline__ int ring_start_chunk(int p, int V, int l0_units) {
+    const int per_view = l0_units + kHiddenUnits;
+    if (p < per_view * V) {
+        const int q = p % per_view;
+        return q < l0_units ? q * kSegChunks : kW16Hidden + (q - l0_units) * kSegChunks;
+    }
+    const int q = p - per_view * V;
+    return q < kHiddenUnits ? kW16Hidden + 192 + q * kSegChunks : kW16Readout;
 }
 
 // issue the LDS-DMA of position p + ahead into slot (c + ahead) % kRing: 2 x 16 B per thread, 1 KiB per wave-instruction
 __device__ __forceinline__ void ring_issue(const Ring& r, int ahead) {
     int pp = r.p + ahead;
     if (pp >= r.P) pp -= r.P;
-    const f32x4* src = r.w16 + (long)ring_start_chunk(pp, r.V, r.per_view) * 64 + r.tid;
+    const f32x4* src = r.w16 + (long)ring_start_chunk(pp, r.V, r.l0_units) * 64 + r.tid;
     f32x4* dst = r.base + ((r.c + ahead) % kRing) * kSegF4 + 64 * r.wave;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 512),
-                                     (__attribute__((address_space(3))) void*)(dst + 512), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * kWgWaves),
+                                     (__attribute__((address_space(3))) void*)(dst + 64 * kWgWaves), 16, 0, 0);
 }
 
 __device__ __forceinline__ const f32x4* ring_cur(const Ring& r) { return r.base + r.c * kSegF4; }
@@ -114,11 +143,16 @@ __device__ __forceinline__ const f32x4* ring_cur(const Ring& r) { return r.base 
 // issue ordinary loads or stores drain everything (their own waits are in-order with the DMA anyway).
 template <bool kDrain>
 __device__ __forceinline__ void ring_next(Ring& r) {
+#if MV16_ABL_BARRIER
+    if (kDrain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#else
     if (kDrain) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+#endif
     r.c = r.c + 1 == kRing ? 0 : r.c + 1;
     r.p = r.p + 1 == r.P ? 0 : r.p + 1;
-    ring_issue(r, kAhead);          // slot (c + 3) % 5 was last read two segments ago; everyone is past that barrier
+    if (!MV16_ABL_DMA) ring_issue(r, kAhead);          // slot (c + 3) % 5 was last read two segments ago; everyone is past that barrier
 }
 
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -152,14 +186,49 @@ __device__ __forceinline__ bf16x8 relu_to_bf16(const f32x16& v, int s) {
 }
 
 // acc += W^T relu(in) for one hidden layer = two 16-chunk segments (input blocks 0,1 then 2,3)
+// The A operands of k-step ks+1 are requested from LDS before the MFMAs of k-step ks are issued (pinned with a
+// sched_barrier: left alone the compiler keeps two A register sets and waits for an LDS round trip per MFMA pair),
+// and the relu / bf16 conversion of the next B operand runs in the shadow of those MFMAs.
+// bfn(ks) -> B operand (bf16x8) of k-step ks of the segment.
+template <typename BFn>
+__device__ __forceinline__ void segment_mfma(Ring& ring, int lane, BFn bfn, f32x16 (&acc)[4]) {
+    const f32x4* wb = ring_cur(ring) + lane;
+#if !MV16_PIPE_A
+#pragma unroll
+    for (int ks = 0; ks < kKs; ++ks) {
+        const bf16x8 bq = bfn(ks);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[nb] = mfma16(__builtin_bit_cast(bf16x8, wb[(ks * 4 + nb) * 64]), bq, acc[nb]);
+    }
+    return;
+#endif
+    f32x4 a[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) a[nb] = wb[nb * 64];
+    bf16x8 b = bfn(0);
+#pragma unroll
+    for (int ks = 0; ks < kKs; ++ks) {
+        f32x4 an[4];
+        if (ks < kKs - 1) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) an[nb] = wb[((ks + 1) * 4 + nb) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[nb] = mfma16(__builtin_bit_cast(bf16x8, a[nb]), b, acc[nb]);
+        if (ks < kKs - 1) {
+            b = bfn(ks + 1);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) a[nb] = an[nb];
+        }
+    }
+}
+
+// acc += W^T relu(in) for one hidden layer: 8 k-steps (input block kb = ks / 2, half ks % 2) in 8 / kKs segments
 __device__ __forceinline__ void dense128_bf16(Ring& ring, int lane, const f32x16 (&in)[4], f32x16 (&acc)[4]) {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const f32x4* wb = ring_cur(ring);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) step16(wb, kk * 2 + s, lane, relu_to_bf16(in[2 * half + kk], s), acc);
+    for (int seg = 0; seg < 8 / kKs; ++seg) {
+        segment_mfma(ring, lane, [&](int ks) { const int g = seg * kKs + ks; return relu_to_bf16(in[g >> 1], g & 1); }, acc);
         ring_next<false>(ring);
     }
 }
@@ -173,7 +242,17 @@ __device__ __forceinline__ void bias_acc(const float* __restrict__ bperm, int h,
         for (int q = 0; q < 4; ++q) {
             const f32x4 v = p[nb * 4 + q];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[nb][4 * q + c] = kAdd ? acc[nb][4 * q + c] + v[c] : v[c];
+            for (int c = 0; c < 4; ++c) {
+                if (kAdd) {
+                    // scalar adds on purpose: left to the compiler these become v_pk_add_f32, which costs the matrix pipe
+                    // of the partner wave far more than two v_add_f32 (MI355X_MICROARCH.md, price of fillers beside MFMAs)
+                    float r = acc[nb][4 * q + c];
+                    asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(r), "v"(v[c]));
+                    acc[nb][4 * q + c] = r;
+                } else {
+                    acc[nb][4 * q + c] = v[c];
+                }
+            }
         }
 }
 
@@ -184,16 +263,16 @@ constexpr int kStage16Row = 256;      // bytes per staged sample row: 128 channe
 // gather.  All gathers run in batches of 4 iterations with their 16 loads issued up front: the 8 waves of the
 // workgroup share the weight ring, hence gather at the same time, and nothing else hides that latency.
 template <bool kMultiView, bool kProj>
-__global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, const f32x4* __restrict__ w16) {
+__global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_bf16_kernel(FieldParams p, const f32x4* __restrict__ w16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
-    constexpr int kRingBytes = kRing * kSegF4 * 16;                       // 80 KiB
+    constexpr int kRingBytes = kRing * kSegF4 * 16;                       // 40 or 80 KiB
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char* stage = smem16 + kRingBytes + wave * (32 * kStage16Row);   // 8 KiB per wave
     // all biases (accumulator order, fp32) live in LDS for the whole kernel: a global bias load in the middle of a
     // segment would make the in-order vmcnt wait drain the weight prefetch issued before it
-    float* net = reinterpret_cast<float*>(smem16 + kRingBytes + 8 * 32 * kStage16Row) - kPackB0;   // net[kPackB0 + i] -> LDS
-    for (int i = tid; i < kPackBr + 8 - kPackB0; i += 512) net[kPackB0 + i] = p.net[kPackB0 + i];
+    float* net = reinterpret_cast<float*>(smem16 + kRingBytes + kWgWaves * 32 * kStage16Row) - kPackB0;   // net[kPackB0 + i] -> LDS
+    for (int i = tid; i < kPackBr + 8 - kPackB0; i += 64 * kWgWaves) net[kPackB0 + i] = p.net[kPackB0 + i];
 
     Ring ring;
     ring.w16 = w16;
@@ -201,8 +280,8 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
     ring.c = 0;
     ring.p = 0;
     ring.V = p.V;
-    ring.per_view = kProj ? 13 : 17;
-    ring.P = ring.per_view * p.V + 13;
+    ring.l0_units = (kProj ? 16 : 80) / kSegChunks;
+    ring.P = (ring.l0_units + kHiddenUnits) * p.V + kHiddenUnits + 1;
     ring.tid = tid;
     ring.wave = wave;
     ring_issue(ring, 0);
@@ -211,9 +290,9 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     ring_issue(ring, kAhead);
 
-    const long n_groups = (p.n_tiles + 7) / 8;
+    const long n_groups = (p.n_tiles + kWgWaves - 1) / kWgWaves;
     for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        long tile = grp * 8 + wave;
+        long tile = grp * kWgWaves + wave;
         const bool tile_ok = tile < p.n_tiles;
         if (!tile_ok) tile = p.n_tiles - 1;                               // idle waves shadow the last tile, no stores
         long g = tile * 32 + j;
@@ -267,7 +346,10 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
                 float sk = 0.0f, ck = 0.0f;
 #pragma unroll
                 for (int k = 0; k < kNFreq; ++k) {
-                    if (k == 0 || k == 5) {
+                    if (MV16_ABL_PE) {
+                        sk = a0;
+                        ck = a0 + 1.0f;
+                    } else if (k == 0 || k == 5) {
                         sincos_f32(a0 * (float)(1 << k), &sk, &ck);
                     } else {
                         const float s2 = sk + sk;
@@ -278,17 +360,16 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
                     pe[d * 10 + k] = h ? ck : sk;
                 }
             }
-            {
-                const f32x4* wb = ring_cur(ring);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
+            for (int seg = 0; seg < 4 / kKs; ++seg) {
+                segment_mfma(ring, lane, [&](int ks) {
                     f32x8 t;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) t[q] = pe[8 * ks + q];
-                    step16(wb, ks, lane, __builtin_convertvector(t, bf16x8), x);
-                }
+                    for (int q = 0; q < 8; ++q) t[q] = pe[8 * (seg * kKs + ks) + q];
+                    return __builtin_convertvector(t, bf16x8);
+                }, x);
+                ring_next<true>(ring);
             }
-            ring_next<true>(ring);
 
             if (kProj) {
                 // ---- texel table: two passes of 64 channels (accumulator blocks nb = 2P, 2P+1 of both lane halves) ----
@@ -300,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
                 for (int P = 0; P < 2; ++P) {                       // unrolled: x[2P + nbl] must be a static register index
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 1
-                    for (int it0 = 0; it0 < 8; it0 += 4) {
+                    for (int it0 = 0; it0 < (MV16_ABL_GATHER ? 0 : 8); it0 += 4) {
                         f32x4 tv[4][4];
                         float axs[4], ays[4];
 #pragma unroll
@@ -347,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
                 const f32x4* fbase = reinterpret_cast<const f32x4*>(p.features) + hf * 32 + j;
                 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 #pragma unroll 1
-                for (int it0 = 0; it0 < 16; it0 += 4) {
+                for (int it0 = 0; it0 < (MV16_ABL_GATHER ? 0 : 16); it0 += 4) {
                     f32x4 tv[4][4];
                     float axs[4], ays[4];
 #pragma unroll
@@ -380,14 +461,11 @@ __global__ __launch_bounds__(512, 2) void field_eval_bf16_kernel(FieldParams p, 
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int part = 0; part < 2; ++part) {
-                    const f32x4* wb = ring_cur(ring);
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const int off = j * kStage16Row + (((2 * (4 * part + ks) + h) ^ (j & 15)) << 4);
-                        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(stage + off);
-                        step16(wb, ks, lane, bq, x);
-                    }
+                for (int part = 0; part < 8 / kKs; ++part) {            // 8 k-steps of 16 channels per 128-channel half
+                    segment_mfma(ring, lane, [&](int ks) {
+                        const int off = j * kStage16Row + (((2 * (kKs * part + ks) + h) ^ (j & 15)) << 4);
+                        return *reinterpret_cast<const bf16x8*>(stage + off);
+                    }, x);
                     ring_next<true>(ring);
                 }
             }
@@ -471,7 +549,7 @@ hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hi
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-    const int lds_bytes = kRing * kSegF4 * 16 + 8 * 32 * kStage16Row + (kPackBr + 8 - kPackB0) * 4;
+    const int lds_bytes = kRing * kSegF4 * 16 + kWgWaves * 32 * kStage16Row + (kPackBr + 8 - kPackB0) * 4;
     {
         std::lock_guard<std::mutex> lock(mtx);
         if (!attr_done[dev]) {
@@ -488,15 +566,16 @@ hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hi
         }
     }
     if ((e = launch_dir_bias(p, stream)) != hipSuccess) return e;
-    const long n_groups = (p.n_tiles + 7) / 8;
-    const unsigned wgs = (unsigned)(n_groups < cus[dev] ? n_groups : cus[dev]);
+    const long n_groups = (p.n_tiles + kWgWaves - 1) / kWgWaves;
+    const long resident = (long)cus[dev] * (8 / kWgWaves);                 // persistent: as many workgroups as fit at once
+    const unsigned wgs = (unsigned)(n_groups < resident ? n_groups : resident);
     const f32x4* w16 = static_cast<const f32x4*>(packed16);
     if (p.V > 1) {
-        if (p.texel_table) hipLaunchKernelGGL((field_eval_bf16_kernel<true, true>), dim3(wgs), dim3(512), lds_bytes, stream, p, w16);
-        else hipLaunchKernelGGL((field_eval_bf16_kernel<true, false>), dim3(wgs), dim3(512), lds_bytes, stream, p, w16);
+        if (p.texel_table) hipLaunchKernelGGL((field_eval_bf16_kernel<true, true>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w16);
+        else hipLaunchKernelGGL((field_eval_bf16_kernel<true, false>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w16);
     } else {
-        if (p.texel_table) hipLaunchKernelGGL((field_eval_bf16_kernel<false, true>), dim3(wgs), dim3(512), lds_bytes, stream, p, w16);
-        else hipLaunchKernelGGL((field_eval_bf16_kernel<false, false>), dim3(wgs), dim3(512), lds_bytes, stream, p, w16);
+        if (p.texel_table) hipLaunchKernelGGL((field_eval_bf16_kernel<false, true>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w16);
+        else hipLaunchKernelGGL((field_eval_bf16_kernel<false, false>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w16);
     }
     return hipGetLastError();
 }
