@@ -46,6 +46,35 @@ def test_argument_validation_without_gpu():
     assert lib.mvnerf_sample_pdf(one, one, one, 4, 33, 64, 0, one, None, None, None) == -2  # only 63 bins is built
 
 
+def test_argument_validation_of_table_and_query_entry_points():
+    lib = _lib.lib()
+    one, odd = ctypes.c_void_p(16), ctypes.c_void_p(20)
+    assert lib.mvnerf_texel_table_bytes(1, 3, 480, 640) == 3 * 480 * 640 * 128 * 4
+    assert lib.mvnerf_texel_table_bytes(0, 1, 8, 8) == 0
+    assert lib.mvnerf_project_texels(one, one, 1, 1, 8, 8, None, None) == -1                     # no table
+    assert lib.mvnerf_project_texels(one, one, 1, 1, 1, 8, one, None) == -1                      # H < 2
+    assert lib.mvnerf_project_texels(one, one, 1, 1, 8, 8, odd, None) == -3                      # misaligned table
+    fe_tail = [one, None, None, None, None, None, one, None]
+    assert lib.mvnerf_field_eval_table(one, one, one, one, one, None, one, one, one, 1, 1, 4, 64, 8, 8, *fe_tail) == -1   # null table
+    assert b'texel_table' in lib.mvnerf_last_error()
+    assert lib.mvnerf_field_eval_table(one, one, one, one, one, odd, one, one, one, 1, 1, 4, 64, 8, 8, *fe_tail) == -3    # misaligned
+    # render_fwd: S must be 64 whether or not tables are given
+    assert lib.mvnerf_render_fwd(*([one] * 10), 1, 1, 4, 32, 8, 8, 0.3, 1.3, 0, one, one, one, one, one, one, 0, None) == -2
+    # query points
+    assert lib.mvnerf_query_workspace_bytes(2, 3, 10) == 2 * 2 * 3 * 10 * 128 * 4
+    assert lib.mvnerf_query_vjp_scratch_bytes(1, 2, 64) == 3 * 2 * 2 * 4096 * 4
+    q_tail = [None, one, one, None]                                    # acts, t_acts, workspace, stream
+    assert lib.mvnerf_query_jvp(*([one] * 9), 1, 1, 0, 8, 8, *q_tail) == -1                       # N = 0
+    assert lib.mvnerf_query_jvp(*([one] * 9), 1, 1, 8, 8, 1, *q_tail) == -2                       # W < 2
+    assert lib.mvnerf_query_jvp(*([one] * 3), None, *([one] * 5), 1, 1, 8, 8, 8, *q_tail) == -1   # no t_dirs
+    v_tail = [one, one, one, None]                                     # scratch, d_points, d_dirs, stream
+    assert lib.mvnerf_query_vjp(*([one] * 9), 1, 2, 40, 8, 8, *v_tail) == -2                      # V > 1 needs N % 32 == 0
+    assert lib.mvnerf_query_vjp(*([one] * 8), odd, 1, 1, 40, 8, 8, *v_tail) == -3                 # misaligned g_acts
+    # bf16 entry point: optional table / fused activations are checked for alignment
+    b_tail = [one, None, None, odd, one, None]                         # rgbs, tap_idx, embedding, acts_fused, workspace, stream
+    assert lib.mvnerf_field_eval_bf16(one, one, one, one, one, None, one, one, one, one, 1, 1, 4, 64, 8, 8, *b_tail) == -3
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     import pytest
     monkeypatch.setattr(_lib, '_lib', None)
