@@ -16,6 +16,9 @@
 #ifndef MV_ASM_RELU
 #define MV_ASM_RELU 0
 #endif
+#ifndef MV_INT_RELU
+#define MV_INT_RELU 1
+#endif
 
 namespace mvnerf {
 
@@ -34,6 +37,14 @@ __device__ __forceinline__ void relu4(const float (&in)[4], float (&b)[4]) {
     asm("v_max_f32_e32 %0, 0, %4\n\tv_max_f32_e32 %1, 0, %5\n\tv_max_f32_e32 %2, 0, %6\n\tv_max_f32_e32 %3, 0, %7\n\ts_nop 1"
         : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
         : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]));
+#elif MV_INT_RELU
+    // relu on the bit pattern: a signed-integer max with 0 zeroes exactly the floats with the sign bit set (-0.0 and
+    // negative NaNs included) and is ONE v_max_i32 - fmaxf costs a canonicalising v_max_f32 pair
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int bits = __builtin_bit_cast(int, in[e]);
+        b[e] = __builtin_bit_cast(float, bits > 0 ? bits : 0);
+    }
 #else
 #pragma unroll
     for (int e = 0; e < 4; ++e) b[e] = fmaxf(in[e], 0.0f);
