@@ -170,6 +170,8 @@ def main():
                 'coarse_launch': {'flop_per_launch': flops_c, 'avg_launch_ms': coarse_ms,
                                   'achieved': flops_c / (coarse_ms * 1e-3) / 1e12},
                 'field_kernel_share_of_step': (coarse_ms + fine_ms) / ms_per_step,
+                # the literal '64 samples/ray' reading of the metric = the coarse pass alone
+                'coarse_only_rays_per_sec': b * r / (coarse_ms * 1e-3),
             }
             if use_table:
                 # `achieved` counts the FLOPs the kernel executes; the reference's graph multiplies the 256 feature
