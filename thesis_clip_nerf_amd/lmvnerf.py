@@ -258,10 +258,24 @@ class LanguageNeRF(nn.Module):
         acts = acts.reshape(N_FUSED, transforms.shape[0], n_points, self.n_transforms_to_check, 128)
         return self.grasp_readout(list(acts.unbind(0)))
 
-    def infer(self, inputs, transforms, n_points_infer, batched_features):
+    def infer(self, inputs, transforms, n_points_infer, batched_features, compute_dtype='f32'):
+        """model_v4.py:208-209.  compute_dtype='bf16' evaluates the trunk on the bf16 MFMA kernel (no gradients there)."""
+        transforms = torch.as_tensor(transforms, dtype=torch.float32).to(self.device_)
         with torch.no_grad():
-            return self._call(inputs, torch.as_tensor(transforms, dtype=torch.float32).to(self.device_), n_points_infer,
-                              batched_features)
+            if compute_dtype == 'f32':
+                return self._call(inputs, transforms, n_points_infer, batched_features)
+            if compute_dtype != 'bf16':
+                raise ValueError("compute_dtype must be 'f32' or 'bf16'")
+            state = self.trunk_state(inputs, batched_features)
+            poses = transforms[:, :, None] @ self.transforms_to_check[None, None]
+            b = transforms.shape[0]
+            points = poses[..., :3, 3].reshape(b, -1, 3).contiguous()
+            dirs = poses[..., :3, 2].reshape(b, -1, 3).contiguous()
+            z = torch.zeros(b, points.shape[1], 1, dtype=torch.float32, device=self.device_)
+            _, acts = ops.field_eval_bf16(points, dirs, z, *state.geo, state.packed, ops.pack_net_bf16(self.trunk_net),
+                                          return_fused_acts=True)
+            acts = acts.reshape(N_FUSED, b, n_points_infer, self.n_transforms_to_check, 128)
+            return self.grasp_readout(list(acts.unbind(0)))
 
     def loss_and_grads(self, data, combined_features):
         """The body of train_step (model_v4.py:277-318) up to the optimizer: returns (dict of losses, prediction)."""
