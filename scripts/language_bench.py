@@ -89,5 +89,5 @@ res = {
 print(f'cfg3 shape: B={b} scenes x {points.shape[1]} query points ({npts} poses x 42 offsets), V={args.views}, {h}x{w}x256 fp32 features '
       f'({feats.numel() * 4 / 1e9:.2f} GB), {n_q} points per pass')
 for k, dt in res.items():
-    n = 2 * n_q if k == 'train_step' else n_q
-    print(f'  {k:14s} {dt * 1e3:8.3f} ms   {n / dt / 1e6:8.2f} M query points/s')
+    n = 2 * n_q if k.startswith('train_step') else n_q
+    print(f'  {k:24s} {dt * 1e3:8.3f} ms   {n / dt / 1e6:8.2f} M query points/s')

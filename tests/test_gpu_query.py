@@ -195,3 +195,4 @@ def test_language_train_step_updates_readout_only():
     scores16 = model.infer(inputs, model.compute_matrices().detach(), 2, sc['features'], compute_dtype='bf16')
     assert scores16.shape == (1, 2)
     assert (scores16 - scores).abs().max().item() < 5e-2 * max(1.0, scores.abs().max().item())     # bf16 trunk, fp32 read-out
+

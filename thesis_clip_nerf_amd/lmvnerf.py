@@ -182,7 +182,8 @@ def rotation_from_6d(r6):
 
 def t_m_to_h_matrix(translations, rot):
     top = torch.cat([rot, translations[..., None]], -1)
-    last = translations.new_tensor([0.0, 0.0, 0.0, 1.0]).expand(translations.shape[:-1] + (1, 4))
+    # (0,0,0,1) built on the device: a host constant would be an H2D copy, which a graph capture refuses
+    last = torch.cat([torch.zeros_like(translations), torch.ones_like(translations[..., :1])], -1)[..., None, :]
     return torch.cat([top, last], -2)
 
 
