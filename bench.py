@@ -178,6 +178,9 @@ def main():
                 # rows per sample, so the same launch stands for more "reference FLOPs" than it runs
                 result['roofline']['reference_flop_per_launch'] = fps_ref * b * r * 2 * s
                 result['roofline']['reference_equiv_tflops'] = fps_ref * b * r * 2 * s / (fine_ms * 1e-3) / 1e12
+                # SURVEY.md 8d's algorithmic figure (491 264 FLOP/sample at V=1) over the same duration; > 1 is possible because
+                # 13 % of those FLOPs are not executed per sample any more - `frac` above is the hardware utilisation
+                result['roofline']['frac_reference_equiv'] = result['roofline']['reference_equiv_tflops'] / peak
                 result['roofline']['project_texels_ms_per_step'] = float(np.mean([e[4].elapsed_time(e[5]) for e in ev]))
             pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
             if os.path.exists(pmc) and not bf16 and args.views == 1 and args.size == 64:   # counters were collected on cfg2
