@@ -185,3 +185,32 @@ def test_train_nerf_loop_checkpoint_and_resume(tmp_path):
     assert other.load(ckpt) and torch.equal(other.fine_net, model.fine_net)
     assert TN.train_model(model, gen, 2, 1, str(tmp_path), ckpt, valid_data, log=logs.append) == []   # nothing left to do
     assert len(TN.train_model(model, gen, 3, 1, str(tmp_path), ckpt, valid_data, log=logs.append)) == 1  # resumes at epoch 2
+
+
+def test_device_resident_generator_matches_host_generator():
+    """the batch assembled on the GPU (host RNG for the pixel indices, mvnerf_get_rays, device gathers) is
+    the batch the host generator builds from the same NumPy RNG state."""
+    from thesis_clip_nerf_amd import train_nerf as TN
+    data = TN.SyntheticSceneDataset(n_scenes=2, n_perspectives=4, height=16, width=20, seed=2)
+    host = TN.MVNeRFDataGenerator(data, n_rays_train=48, batch_size=2, n_views=2, shuffle=False)
+    devg = TN.MVNeRFDataGenerator(data, n_rays_train=48, batch_size=2, n_views=2, shuffle=False, device=DEV)
+    np.random.seed(7)
+    (h_in, h_feat), h_tgt = host[0]
+    np.random.seed(7)
+    (d_in, d_feat), d_tgt = devg[0]
+    assert d_in[0].device.type == 'cuda' and d_feat.device.type == 'cuda'
+    for name, a, b in zip(['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'], h_in, d_in):
+        assert tuple(a.shape) == tuple(b.shape), name
+        assert np.abs(a - b.cpu().numpy()).max() < 1e-6, name
+    assert np.array_equal(h_feat, d_feat.cpu().numpy())
+    assert np.abs(h_tgt - d_tgt.cpu().numpy()).max() < 1e-7
+    # second batch re-uses the resident views and still follows the host RNG
+    np.random.seed(8)
+    (_, _), h_tgt2 = host[0]
+    np.random.seed(8)
+    (_, _), d_tgt2 = devg[0]
+    assert np.abs(h_tgt2 - d_tgt2.cpu().numpy()).max() < 1e-7
+    model = MVVNeRFRenderer(48, 512, n_views=2, batch_size=2, near=0.3, far=1.3, device=DEV)
+    TN.compile_model(model)
+    out = model.train_step((d_in, d_tgt), combined_features=d_feat)
+    assert np.isfinite(float(out['loss']))

@@ -56,7 +56,13 @@ class MVNeRFDataGenerator:
     """data_generator/mvnerf.py + base.py: keras-Sequence semantics, NumPy RNG exactly as the reference
     (np.random.choice of views, bbox_biased_sample of pixels).  Returns ((inputs 5-tuple, features), targets)."""
 
-    def __init__(self, dataset, n_rays_train=512, batch_size=1, n_views=2, shuffle=True):
+    def __init__(self, dataset, n_rays_train=512, batch_size=1, n_views=2, shuffle=True, device=None):
+        """device: keep every view (colours, features, cameras) resident on that GPU after its first use and build the
+        batch there - pixel indices still come from the host NumPy RNG (the reference's stream, mvnerf.py:16-25), rays
+        from mvnerf_get_rays on their (u, v), targets from a device gather; per step only the (n, 2) indices cross PCIe
+        instead of V x H x W x (3 + 256) floats."""
+        self.device = torch.device(device) if device is not None else None
+        self._resident = {}
         self.dataset = dataset
         self.n_rays_train = n_rays_train
         self.batch_size = batch_size
@@ -91,7 +97,50 @@ class MVNeRFDataGenerator:
     def get_target(color, rays):
         return np.array(color[rays[:, 0], rays[:, 1], :3]) / 255.0                       # mvnerf.py:45-48
 
+    def _view(self, i, p):
+        """Device-resident (image float (H,W,3) in [0,1], colour uint8, features, E^-1, K4) of scene i, perspective p."""
+        key = (int(i), int(p))
+        if key not in self._resident:
+            dev = self.device
+            color = np.ascontiguousarray(self.dataset.colors[i][p][..., :3])
+            einv, k4 = camera_parameters(self.dataset.cameras[i][p])
+            self._resident[key] = (torch.from_numpy((color / 255.0).astype(np.float32)).to(dev),
+                                   torch.from_numpy(color).to(dev),
+                                   torch.from_numpy(np.asarray(self.dataset.features[i][p], dtype=np.float32)).to(dev),
+                                   torch.from_numpy(einv.astype(np.float32)).to(dev), torch.from_numpy(k4.astype(np.float32)).to(dev))
+        return self._resident[key]
+
+    def get_data_device(self, batch):
+        """get_data with the batch assembled on the GPU; consumes the NumPy RNG exactly like get_data."""
+        from . import ops
+        dev = self.device
+        ro, rd, imgs, ks, es, feats, targets = [], [], [], [], [], [], []
+        for i in batch:
+            idx = np.random.choice(range(self.n_perspectives), size=self.n_views + 1, replace=False)
+            src, tgt = idx[:-1], idx[-1]
+            color = self.dataset.colors[i][tgt]
+            cam = self.dataset.cameras[i][tgt]
+            rays = bbox_biased_sample(self.n_rays_train, np.array([0, 0, color.shape[0], color.shape[1]]), color.shape[0], color.shape[1])
+            k = np.reshape(cam['intrinsics'], (3, 3)).astype(np.float32)
+            m = cam['pose'][:3, :3] @ np.linalg.inv(k)                                    # as generate_rays (host LAPACK)
+            px = torch.from_numpy(np.ascontiguousarray(rays)).to(dev)                      # (n,2) int64 (row, col)
+            r_o, r_d = ops.get_rays_device(m, cam['pose'][:3, -1], dev, u=px[:, 1].to(torch.float32).contiguous(),
+                                           v=px[:, 0].to(torch.float32).contiguous())
+            tgt_color = self._view(i, tgt)[1]
+            targets.append(tgt_color[px[:, 0], px[:, 1]].to(torch.float32) / 255.0)
+            views = [self._view(i, s_) for s_ in src]
+            ro.append(r_o)
+            rd.append(r_d)
+            imgs.append(torch.stack([v_[0] for v_ in views]))
+            feats.append(torch.stack([v_[2] for v_ in views]))
+            es.append(torch.stack([v_[3] for v_ in views]))
+            ks.append(torch.stack([v_[4] for v_ in views]))
+        st = torch.stack
+        return ((st(ro), st(rd), st(imgs), st(ks), st(es)), st(feats)), st(targets)
+
     def get_data(self, batch):
+        if self.device is not None:
+            return self.get_data_device(batch)
         ro, rd, imgs, ks, es, feats, targets = [], [], [], [], [], [], []
         for i in batch:
             idx = np.random.choice(range(self.n_perspectives), size=self.n_views + 1, replace=False)
@@ -183,6 +232,7 @@ def main(argv=None):
     ap.add_argument('--batch-size', type=int, default=1)
     ap.add_argument('--n-rays', type=int, default=512)
     ap.add_argument('--size', type=int, default=32)
+    ap.add_argument('--host-batches', action='store_true', help='assemble batches in NumPy on the host (default: on the GPU)')
     args = ap.parse_args(argv)
     train = SyntheticSceneDataset(n_scenes=8, height=args.size, width=args.size, seed=0)
     valid = SyntheticSceneDataset(n_scenes=1, height=args.size, width=args.size, seed=1)
@@ -192,7 +242,8 @@ def main(argv=None):
                   'tgt_camera_config': valid.cameras[0][args.n_views],
                   'tgt_colors': valid.colors[0][args.n_views],
                   'combined_features': torch.from_numpy(np.array([[valid.features[0][i] for i in src]], dtype=np.float32))}
-    gen = MVNeRFDataGenerator(train, n_rays_train=args.n_rays, batch_size=args.batch_size, n_views=args.n_views)
+    gen = MVNeRFDataGenerator(train, n_rays_train=args.n_rays, batch_size=args.batch_size, n_views=args.n_views,
+                              device=None if args.host_batches else 'cuda:0')
     model = MVVNeRFRenderer(args.n_rays, 512, n_views=args.n_views, batch_size=args.batch_size, near=0.3, far=1.3)
     compile_model(model)
     ckpt = f'{args.model_path}/model_final'
