@@ -13,6 +13,8 @@
 // per SIMD).  relu' is taken from the primal pre-activation in registers - nothing is stashed in HBM.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "mvnerf_kernels.h"
 #include "mvnerf_math.h"
 #include "mvnerf_pack.h"
@@ -273,17 +275,17 @@ __global__ __launch_bounds__(256) void dir_seed_tangent_kernel(FieldParams p) {
 }
 
 hipError_t launch_field_jvp(const FieldParams& p, hipStream_t stream) {
-    static bool attr_done[16] = {};
+    static std::atomic<bool> attr_done[16];      // first call per device sets the dynamic-LDS limit (idempotent)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const int lds_bytes = 4 * 2 * kTile * kStageRow * 4;           // 128 KiB
-    if (dev >= 0 && dev < 16 && !attr_done[dev]) {
+    if (dev >= 0 && dev < 16 && !attr_done[dev].load(std::memory_order_acquire)) {
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_jvp_kernel<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess) return e;
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_jvp_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess) return e;
-        attr_done[dev] = true;
+        attr_done[dev].store(true, std::memory_order_release);
     }
     const long rows = (long)p.B * p.V * p.R;
     hipLaunchKernelGGL(dir_seed_tangent_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);

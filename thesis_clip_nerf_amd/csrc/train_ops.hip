@@ -13,6 +13,8 @@
 // the sample positions, Adam with clip-by-value.  See DESIGN.md section 8.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "mvnerf_kernels.h"
 #include "mvnerf_math.h"
 #include "mvnerf_mfma.h"
@@ -419,15 +421,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 hipError_t launch_block_bwd_fused(const float* g_tl, const float* hid_tl, const float* x_tl, const float* w2t, const float* w1t,
                                   float* dx_tl, long n_tiles, float* dW2, float* db2, float* dW1, float* db1, int max_wgs,
                                   hipStream_t st) {
-    static bool attr_done[16] = {};
+    static std::atomic<bool> attr_done[16];      // first call per device sets the dynamic-LDS limit (idempotent)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const int lds_bytes = 4 * 16384;
-    if (dev >= 0 && dev < 16 && !attr_done[dev]) {
+    if (dev >= 0 && dev < 16 && !attr_done[dev].load(std::memory_order_acquire)) {
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      lds_bytes)) != hipSuccess) return e;
-        attr_done[dev] = true;
+        attr_done[dev].store(true, std::memory_order_release);
     }
     const unsigned wgs = (unsigned)(n_tiles < max_wgs ? n_tiles : max_wgs);
     hipLaunchKernelGGL(block_bwd_fused_kernel, dim3(wgs), dim3(256), lds_bytes, st, g_tl, hid_tl, x_tl, w2t, w1t, dx_tl, n_tiles, dW2,
@@ -1060,15 +1062,15 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
 hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, float* d_o,
                            float* d_d, hipStream_t st) {
     const size_t lds_bytes = (size_t)4 * (32 * kDfeRow + 64) * sizeof(float);
-    static bool attr_done[16] = {};
+    static std::atomic<bool> attr_done[16];      // first call per device sets the dynamic-LDS limit (idempotent)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 16 && !attr_done[dev]) {
+    if (dev >= 0 && dev < 16 && !attr_done[dev].load(std::memory_order_acquire)) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_dz_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes);
         if (e != hipSuccess) return e;
-        attr_done[dev] = true;
+        attr_done[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(field_dz_kernel, dim3((unsigned)((p.n_tiles * p.V + 3) / 4)), dim3(256), lds_bytes, st, p, g0_tl, w0t_streams, d_z, d_o, d_d);
     return hipGetLastError();
