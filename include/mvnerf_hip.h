@@ -232,12 +232,15 @@ int mvnerf_resample_bwd(const float* z, const float* weights, const float* u_fin
  * order, caller zeroes it) given d_rgbs (B,R,S,4).  Inputs as in the forward call, plus net_keras, the
  * transposed streams and the stash.
  * d_z (optional, may be NULL): (B,R,S), INCREMENTED by the gradient w.r.t. the sample depths through the sample
- * positions (positional encoding of the camera point and the bilinear lerp factors). */
+ * positions (positional encoding of the camera point and the bilinear lerp factors).
+ * d_features (optional, may be NULL): (B,V,H,W,256), INCREMENTED by the gradient w.r.t. the source feature maps
+ * (combined_features is produced by trainable encoders in the reference, train_nerf.py:27-32; this is what flows
+ * back to them). */
 int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float* z, const float* images,
                           const float* features, const float* intrinsics, const float* extrinsics_inv,
                           const float* net_keras, const float* bwd_streams, const float* stash, const float* rgbs,
                           const float* d_rgbs, int B, int V, int R, int S, int H, int W, void* scratch, float* grad,
-                          float* d_z, mvnerf_stream_t stream);
+                          float* d_z, float* d_features, mvnerf_stream_t stream);
 
 /* ---- The trunk as a differentiable field on arbitrary query points. ----
  * Reference consumer: LanguageNeRF._call (lmvnerf/model_v4.py:208-265) evaluates fine_embedding on

@@ -209,17 +209,19 @@ def render_call(coarse_flat, fine_flat, o, d, images, k4, einv, features, near, 
     return rgb, depth, fine_rgb, fine_depth
 
 
-def train_loss_and_grads(coarse_flat, fine_flat, labels, scene, dtype=torch.float64, stop_fine_z=False):
+def train_loss_and_grads(coarse_flat, fine_flat, labels, scene, dtype=torch.float64, stop_fine_z=False, feature_grad=False):
     """model_v0.py:190-194: loss = MSE(labels, rgb) + MSE(labels, fine_rgb); returns loss and the two flat
-    gradient vectors (Keras MeanSquaredError: mean over every element)."""
+    gradient vectors (Keras MeanSquaredError: mean over every element); with feature_grad also dL/d(features)."""
     def t(a):
         return torch.as_tensor(np.asarray(a)).to(dtype)
     cf = t(coarse_flat).clone().requires_grad_(True)
     ff = t(fine_flat).clone().requires_grad_(True)
+    feats = t(scene['features']).clone().requires_grad_(feature_grad)
     out = render_call(cf, ff, t(scene['rays_o']), t(scene['rays_d']), t(scene['images']), t(scene['intrinsics']),
-                      t(scene['extrinsics_inv']), t(scene['features']), scene['near'], scene['far'], scene['n_samples'],
+                      t(scene['extrinsics_inv']), feats, scene['near'], scene['far'], scene['n_samples'],
                       t(scene['u_coarse']), t(scene['u_fine']), stop_fine_z=stop_fine_z)
     y = t(labels)
     loss = ((y - out[0]) ** 2).mean() + ((y - out[2]) ** 2).mean()
     loss.backward()
-    return loss.item(), cf.grad.numpy(), ff.grad.numpy(), [o.detach().numpy() for o in out]
+    res = (loss.item(), cf.grad.numpy(), ff.grad.numpy(), [o.detach().numpy() for o in out])
+    return res + (feats.grad.numpy(),) if feature_grad else res

@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--rays', type=int, default=4096)
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--size', type=int, default=64)
+ap.add_argument('--feature-grad', action='store_true', help='also time loss_and_grads with dL/d(combined_features)')
 args = ap.parse_args()
 dev = 'cuda:0'
 sc = make_scene(seed=0, height=args.size, width=args.size, n_rays=None if args.rays == args.size ** 2 else args.rays)
@@ -37,3 +38,22 @@ for _ in range(args.steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
 print(f'train_step: {r} rays, {dt*1e3:.2f} ms/step = {r/dt:.0f} rays/s (fwd+bwd+Adam), loss {float(out["loss"]):.5f}')
+
+if args.feature_grad:
+    for _ in range(2):
+        m.loss_and_grads(inputs, y, feats, u_coarse=uc, u_fine=uf, return_d_features=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.loss_and_grads(inputs, y, feats, u_coarse=uc, u_fine=uf, return_d_features=True)
+    torch.cuda.synchronize()
+    dt2 = (time.perf_counter() - t0) / args.steps
+    for _ in range(2):
+        m.loss_and_grads(inputs, y, feats, u_coarse=uc, u_fine=uf)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.loss_and_grads(inputs, y, feats, u_coarse=uc, u_fine=uf)
+    torch.cuda.synchronize()
+    dt1 = (time.perf_counter() - t0) / args.steps
+    print(f'loss_and_grads: {dt1*1e3:.2f} ms; with dL/d(features) ({feats.numel()*4/1e6:.1f} MB map): {dt2*1e3:.2f} ms')

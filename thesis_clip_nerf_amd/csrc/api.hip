@@ -381,7 +381,7 @@ int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float*
                           const float* features, const float* intrinsics, const float* extrinsics_inv,
                           const float* net_keras, const float* bwd_streams, const float* stash, const float* rgbs,
                           const float* d_rgbs, int B, int V, int R, int S, int H, int W, void* scratch, float* grad,
-                          float* d_z, mvnerf_stream_t stream) {
+                          float* d_z, float* d_features, mvnerf_stream_t stream) {
     using namespace mvnerf;
     if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !net_keras || !bwd_streams ||
         !stash || !rgbs || !d_rgbs || !scratch || !grad)
@@ -438,7 +438,8 @@ int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float*
     p.k4 = intrinsics; p.einv = extrinsics_inv;
     p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W; p.total = total; p.n_tiles = n_tiles;
     MV_TRY(launch_dw0(p, buf[g], grad + kKerasW0, grad + kKerasB0, kBwdMaxWGs, st));
-    if (d_z) MV_TRY(launch_field_dz(p, buf[g], bwd_streams + (size_t)12 * kHiddenWFloats, d_z, nullptr, nullptr, st));
+    if (d_z || d_features)
+        MV_TRY(launch_field_dz(p, buf[g], bwd_streams + (size_t)12 * kHiddenWFloats, d_z, nullptr, nullptr, d_features, st));
 #undef MV_TRY
     return 0;
 }
@@ -526,7 +527,7 @@ int mvnerf_query_vjp(const float* points, const float* dirs, const float* images
     p.rays_o = points; p.rays_d = dirs; p.z = nullptr; p.images = images; p.features = features;
     p.k4 = intrinsics; p.einv = extrinsics_inv;
     p.B = B; p.V = V; p.R = N; p.S = 1; p.H = H; p.W = W; p.total = total; p.n_tiles = n_tiles;
-    MV_TRY(launch_field_dz(p, buf[g], bwd_streams + (size_t)12 * kHiddenWFloats, nullptr, d_points, d_dirs, st));
+    MV_TRY(launch_field_dz(p, buf[g], bwd_streams + (size_t)12 * kHiddenWFloats, nullptr, d_points, d_dirs, nullptr, st));
 #undef MV_TRY
     return 0;
 }

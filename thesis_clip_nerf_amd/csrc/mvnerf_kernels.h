@@ -77,7 +77,7 @@ hipError_t launch_finish_view(const float* rgb, const float* depth, long n, floa
 // train_ops.hip
 hipError_t launch_pack_dense(const float* src, int transpose, int valid_rows, float* dst, hipStream_t st);
 hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, float* d_o,
-                           float* d_d, hipStream_t st);
+                           float* d_d, float* d_features, hipStream_t st);
 hipError_t launch_rows_to_tl(const float* rows, long n_rows, long n_tiles, int accumulate, float* out_tl, hipStream_t st);
 hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int g_feats, long n_tiles, float* dW, int ldn,
                           int n_valid, float* db, int max_wgs, hipStream_t st);

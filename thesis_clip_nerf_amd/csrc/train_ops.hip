@@ -893,7 +893,8 @@ constexpr int kDfeRow = 257;       // floats per sample row of the LDS image (od
 // instead of dL/dz - the PE(cam dir) rows 60..119 then count too (cam dir = E^-1 [d; 1], Q3).
 __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const float* __restrict__ g0_tl,
                                                           const float* __restrict__ w0t_streams, float* __restrict__ d_z,
-                                                          float* __restrict__ d_o, float* __restrict__ d_d) {
+                                                          float* __restrict__ d_o, float* __restrict__ d_d,
+                                                          float* __restrict__ d_features) {
     extern __shared__ __attribute__((aligned(16))) float lds_dz[];
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1006,6 +1007,7 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
         const int tls = __shfl(tl, sidx);
         const float axs = __shfl(tp.ax, sidx), ays = __shfl(tp.ay, sidx);
         const float* f = p.features + 256 * (long)tls;
+        const bool live = __shfl((int)valid, sidx) != 0;
         float pa = 0.0f, pb = 0.0f;
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
@@ -1014,6 +1016,15 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
             const float vtl = f[c], vtr = f[256 + c], vbl = f[256 * (long)p.W + c], vbr = f[256 * (long)p.W + 256 + c];
             pa += v * ((1.0f - ays) * (vtr - vtl) + ays * (vbr - vbl));
             pb += v * ((vbl - vtl) + axs * ((vbr - vbl) - (vtr - vtl)));
+            if (d_features && live) {
+                // gradient w.r.t. the source feature map: the sample's dL/d(lerped features) goes back to its four taps
+                // with the bilinear weights (the scatter of SURVEY.md 7.7; what an upstream encoder trains on)
+                float* df = d_features + 256 * (long)tls + c;
+                atomicAdd(df, v * ((1.0f - axs) * (1.0f - ays)));
+                atomicAdd(df + 256, v * (axs * (1.0f - ays)));
+                atomicAdd(df + 256 * (long)p.W, v * ((1.0f - axs) * ays));
+                atomicAdd(df + 256 * (long)p.W + 256, v * (axs * ays));
+            }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -1060,7 +1071,7 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
 }
 
 hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, float* d_o,
-                           float* d_d, hipStream_t st) {
+                           float* d_d, float* d_features, hipStream_t st) {
     const size_t lds_bytes = (size_t)4 * (32 * kDfeRow + 64) * sizeof(float);
     static std::atomic<bool> attr_done[16];      // first call per device sets the dynamic-LDS limit (idempotent)
     int dev = 0;
@@ -1072,7 +1083,7 @@ hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float
         if (e != hipSuccess) return e;
         attr_done[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(field_dz_kernel, dim3((unsigned)((p.n_tiles * p.V + 3) / 4)), dim3(256), lds_bytes, st, p, g0_tl, w0t_streams, d_z, d_o, d_d);
+    hipLaunchKernelGGL(field_dz_kernel, dim3((unsigned)((p.n_tiles * p.V + 3) / 4)), dim3(256), lds_bytes, st, p, g0_tl, w0t_streams, d_z, d_o, d_d, d_features);
     return hipGetLastError();
 }
 

@@ -192,12 +192,14 @@ class MVVNeRFRenderer:
         self._train_bufs = {}
 
     def loss_and_grads(self, inputs, labels, combined_features, u_coarse=None, u_fine=None, generator=None,
-                       stop_fine_z=False):
+                       stop_fine_z=False, return_d_features=False):
         """Forward + backward of loss = MSE(labels, rgb) + MSE(labels, fine_rgb) (model_v0.py:190-194).
         Returns (loss 1-element device tensor, flat gradient (2 x 247300): [coarse | fine], outputs 4-tuple).
         Gradient scope: all MLP variables, including the path the reference leaves open (no stop_gradient on the
         importance samples): fine loss -> fine sample positions -> sample_pdf -> coarse weights ->
-        coarse network.  stop_fine_z=True cuts that path (cheaper)."""
+        coarse network.  stop_fine_z=True cuts that path (cheaper).
+        return_d_features: also return dL/d(combined_features) (B,V,H,W,256) as a 4th element - the cotangent an
+        upstream feature encoder (trained in the reference, train_nerf.py:27-32) continues from."""
         if not hasattr(self, '_grad'):
             self.compile()
         rays_o, rays_d, images, k4, einv = [self._dev(t) for t in inputs]
@@ -231,13 +233,16 @@ class MVVNeRFRenderer:
             d_rgbs_f, d_z_all, d_w = ops.composite_bwd(z_all, rgbs_f, d_fine), None, None
         else:
             d_rgbs_f, d_z_all = ops.composite_bwd(z_all, rgbs_f, d_fine, return_dz=True)
+        d_feat = torch.zeros_like(feats) if return_d_features else None
         tb['scratch'] = ops.field_backward(rays_o, rays_d, z_all, *geo, self.fine_net, self._packed_bwd[1], tb['stash_f'],
-                                           rgbs_f, d_rgbs_f, gf, tb.get('scratch'), d_z=d_z_all)
+                                           rgbs_f, d_rgbs_f, gf, tb.get('scratch'), d_z=d_z_all, d_features=d_feat)
         if not stop_fine_z:
             d_w = ops.resample_bwd(z, w, self._dev(u_fine), rank, d_z_all, self.q7_mode)
         d_rgbs_c = ops.composite_bwd(z, rgbs_c, d_rgb, d_weights=d_w)
         tb['scratch'] = ops.field_backward(rays_o, rays_d, z, *geo, self.coarse_net, self._packed_bwd[0], tb['stash_c'],
-                                           rgbs_c, d_rgbs_c, gc, tb['scratch'])
+                                           rgbs_c, d_rgbs_c, gc, tb['scratch'], d_features=d_feat)
+        if return_d_features:
+            return loss, self._grad, (rgb, depth, fine_rgb, fine_depth), d_feat
         return loss, self._grad, (rgb, depth, fine_rgb, fine_depth)
 
     def train_step(self, data, combined_features=None, u_coarse=None, u_fine=None, generator=None, stop_fine_z=False):
