@@ -236,3 +236,33 @@ def test_feature_map_gradient_matches_torch_oracle(batch, views, stop):
     assert rel < (8e-2 if not stop else 6e-3), rel
     # texels no sample touches receive exactly nothing
     assert np.array_equal(got == 0, want == 0) or np.abs(got[want == 0]).max() < 1e-9
+
+
+def test_train_step_trains_an_upstream_torch_encoder():
+    """train_nerf.py:27-32 also optimises the feature encoders: with an encoder_optimizer, train_step back-propagates the HIP
+    path's dL/d(combined_features) into a torch encoder; its weight gradient equals autograd through the torch twin."""
+    sc = make_scene(seed=80, batch=1, n_views=2, height=12, width=12, n_rays=32, bias_scale=0.05)
+    y = np.random.default_rng(4).random((1, 32, 3)).astype(np.float32)
+    torch.manual_seed(0)
+    enc = torch.nn.Linear(3, 256).to(DEV)                  # a 1x1 "conv" on NHWC images: (N,H,W,3) -> (N,H,W,256)
+    w0, b0 = enc.weight.detach().clone(), enc.bias.detach().clone()
+    m = MVVNeRFRenderer(32, 32, n_views=2, batch_size=1, near=sc['near'], far=sc['far'], device=DEV, feature_encoder=enc)
+    m.set_weights(sc['coarse'], sc['fine'])
+    opt = torch.optim.SGD(enc.parameters(), lr=0.0)       # lr 0: keep the weights, inspect the gradient
+    m.compile(learning_rate=0.0, encoder_optimizer=opt)
+    inputs = tuple(sc[k] for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'])
+    m.train_step((inputs, y), u_coarse=dev(sc['u_coarse']), u_fine=dev(sc['u_fine']), stop_fine_z=True)
+    torch.cuda.synchronize()
+    got_w, got_b = enc.weight.grad.double().cpu(), enc.bias.grad.double().cpu()
+    # float64 twin: same encoder, features = images @ W^T + b, loss through the torch oracle
+    W = w0.double().cpu().requires_grad_(True)
+    bb = b0.double().cpu().requires_grad_(True)
+    t = lambda k: torch.as_tensor(sc[k]).double()
+    feats = t('images') @ W.T + bb
+    out = T.render_call(t('coarse'), t('fine'), t('rays_o'), t('rays_d'), t('images'), t('intrinsics'), t('extrinsics_inv'), feats,
+                        sc['near'], sc['far'], sc['n_samples'], t('u_coarse'), t('u_fine'), stop_fine_z=True)
+    yy = torch.as_tensor(y).double()
+    (((yy - out[0]) ** 2).mean() + ((yy - out[2]) ** 2).mean()).backward()
+    clip = lambda g: g.clamp(-1.0, 1.0)                    # train_step clips by value before the optimizer step
+    assert (got_w - clip(W.grad)).norm() < 6e-3 * clip(W.grad).norm()
+    assert (got_b - clip(bb.grad)).norm() < 6e-3 * clip(bb.grad).norm()

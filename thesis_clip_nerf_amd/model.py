@@ -173,7 +173,7 @@ class MVVNeRFRenderer:
 
     # ---- training (model_v0.py:186-197, train_nerf.py:20-34, nerf_utils.py:8-12) -----------------------------
     def compile(self, learning_rate=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7, gradients_clip=1.0,
-                train_readout=False, grad_sync=None):
+                train_readout=False, grad_sync=None, encoder_optimizer=None):
         """train_nerf.py:20-34: MSE loss, Adam(1e-4) on the coarse and fine embeddings.
         `learning_rate` may be a callable of the step (e.g. nerf_utils.WarmupScheduler).
         train_readout=False mirrors the reference's MultiOptimizer list, which names only the two embeddings
@@ -190,6 +190,9 @@ class MVVNeRFRenderer:
         self._update_mask = torch.cat([mask, mask]).contiguous()
         self._grad_sync = grad_sync
         self._train_bufs = {}
+        # optional torch optimizer over the parameters of `feature_encoder` (a torch.nn.Module): train_step then also
+        # back-propagates dL/d(combined_features) into the encoder (used only when train_step encodes the images itself)
+        self._encoder_optimizer = encoder_optimizer
 
     def loss_and_grads(self, inputs, labels, combined_features, u_coarse=None, u_fine=None, generator=None,
                        stop_fine_z=False, return_d_features=False):
@@ -248,11 +251,27 @@ class MVVNeRFRenderer:
     def train_step(self, data, combined_features=None, u_coarse=None, u_fine=None, generator=None, stop_fine_z=False):
         """model_v0.py:186-197: one optimisation step on (inputs, labels); returns {'loss': 1-element tensor}."""
         inputs, labels = data
+        enc_opt = getattr(self, '_encoder_optimizer', None)
+        train_encoder = combined_features is None and enc_opt is not None
         if combined_features is None:
             bsz, v = inputs[2].shape[:2]
-            feats = self.encode(self._dev(inputs[2]).reshape(bsz * v, *inputs[2].shape[2:]))
-            combined_features = feats.reshape(bsz, v, *feats.shape[1:])
-        loss, grad, _ = self.loss_and_grads(inputs, labels, combined_features, u_coarse, u_fine, generator, stop_fine_z)
+            with torch.set_grad_enabled(train_encoder):
+                feats = self.encode(self._dev(inputs[2]).reshape(bsz * v, *inputs[2].shape[2:]))
+                combined_features = feats.reshape(bsz, v, *feats.shape[1:])
+        if train_encoder:
+            # the reference's optimizer list also names the feature encoders (train_nerf.py:27-32): the HIP backward hands
+            # dL/d(combined_features) back to torch autograd, which continues into the encoder's variables
+            loss, grad, _, d_feat = self.loss_and_grads(inputs, labels, combined_features.detach().contiguous(), u_coarse, u_fine,
+                                                        generator, stop_fine_z, return_d_features=True)
+            enc_opt.zero_grad(set_to_none=True)
+            combined_features.backward(d_feat)
+            for group in enc_opt.param_groups:           # optimize(): clip-by-value, then the optimizer step
+                for prm in group['params']:
+                    if prm.grad is not None:
+                        prm.grad.clamp_(-self._opt['clip'], self._opt['clip'])
+            enc_opt.step()
+        else:
+            loss, grad, _ = self.loss_and_grads(inputs, labels, combined_features, u_coarse, u_fine, generator, stop_fine_z)
         if self._grad_sync is not None:
             self._grad_sync(grad)                         # one flat collective for both MLPs
         o = self._opt
