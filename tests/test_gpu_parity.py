@@ -87,6 +87,29 @@ def test_field_eval_texel_table_matches_oracle(n_views, hw, seed):
     assert (torch.from_numpy(rgbs).to(DEV) - rgbs_direct).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize('case', range(6))
+def test_field_eval_random_shapes(case):
+    """Odd image sizes, 1..4 views, batches, ray / sample counts that leave ragged tiles - direct and texel-table paths."""
+    rng = np.random.default_rng(100 + case)
+    views, batch = int(rng.integers(1, 5)), int(rng.integers(1, 3))
+    hw = (int(rng.integers(5, 40)), int(rng.integers(5, 40)))
+    n_rays, s = int(rng.integers(1, 50)), int(rng.choice([1, 7, 33, 64, 100]))
+    sc = make_scene(seed=200 + case, batch=batch, height=hw[0], width=hw[1], n_views=views, n_rays=n_rays, bias_scale=0.1)
+    d = scene_to_dev(sc)
+    z = np.sort(rng.uniform(sc['near'], sc['far'], (batch, n_rays, s)).astype(np.float32), -1)
+    net = O.unflatten_net(sc['fine'])
+    rgb_ref, sig_ref, taps_ref = O.field_eval(net, sc['rays_o'], sc['rays_d'], z, sc['images'], sc['features'],
+                                              sc['intrinsics'], sc['extrinsics_inv'], return_taps=True)
+    packed = ops.pack_net(d['fine'])
+    args = (d['rays_o'], d['rays_d'], dev(z), d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'], packed)
+    for table in (None, ops.project_texels(d['features'], packed)):
+        rgbs, taps = ops.field_eval(*args, return_taps=True, texel_table=table)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(taps.cpu().numpy(), taps_ref)
+        rgbs = rgbs.cpu().numpy()
+        assert np.abs(rgbs[..., :3] - rgb_ref).max() < TOL and np.abs(rgbs[..., 3] - sig_ref).max() < TOL, (views, batch, hw, n_rays, s)
+
+
 def test_field_eval_ragged_tail_and_fine_count():
     # total samples not a multiple of the 32-sample wave tile; S = 128 as in the fine pass
     sc = make_scene(seed=4, height=16, width=16, n_rays=3)
