@@ -51,6 +51,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--views', type=int, default=1)
     ap.add_argument('--size', type=int, default=64, help='source/target image side (rays = size^2)')
+    ap.add_argument('--height', type=int, default=0, help='source image height (default: --size)')
+    ap.add_argument('--width', type=int, default=0, help='source image width (default: --size)')
+    ap.add_argument('--rays', type=int, default=0, help='random target pixels instead of every pixel of a size x size view (e.g. cfg5: 16384 rays, 480x640 sources)')
     ap.add_argument('--cpu-rays', type=int, default=512, help='rays of the bounded CPU-baseline sample (0 = skip)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='bf16: both field passes on the bf16 MFMA kernel (configs 3/5; not the headline)')
     ap.add_argument('--texel-table', default='auto', choices=['auto', 'on', 'off'],
@@ -83,7 +86,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    sc = make_scene(seed=rank, batch=1, n_views=args.views, height=args.size, width=args.size)
+    img_h, img_w = args.height or args.size, args.width or args.size
+    sc = make_scene(seed=rank, batch=1, n_views=args.views, height=img_h, width=img_w, n_rays=args.rays or None)
     t = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in
          ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'u_coarse', 'u_fine', 'coarse', 'fine']}
     pc, pf = ops.pack_net(t['coarse']), ops.pack_net(t['fine'])
@@ -95,8 +99,8 @@ def main():
     near, far = sc['near'], sc['far']
     field_args = (t['images'], t['features'], t['intrinsics'], t['extrinsics_inv'])
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
-    use_table = args.texel_table == 'on' or (args.texel_table == 'auto' and ops.texel_table_pays(r, s, args.size, args.size))
-    tables = torch.empty((2, b, args.views, args.size, args.size, 128), dtype=torch.float32, device=dev) if use_table else None
+    use_table = args.texel_table == 'on' or (args.texel_table == 'auto' and ops.texel_table_pays(r, s, img_h, img_w))
+    tables = torch.empty((2, b, args.views, img_h, img_w, 128), dtype=torch.float32, device=dev) if use_table else None
 
     def step_ops(e=None):
         tab_c = tab_f = None
@@ -142,8 +146,8 @@ def main():
         'metric': 'rendered_rays_per_sec', 'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-        'config': {'workload': f'cfg2: _call on B=1 scene/GPU, V={args.views} source view {args.size}x{args.size}x(3+256) fp32, '
-                               f'R={r} rays (all pixels of a {args.size}x{args.size} target), 64 coarse + 128 fine samples/ray, '
+        'config': {'workload': f'cfg2: _call on B=1 scene/GPU, V={args.views} source view {img_h}x{img_w}x(3+256) fp32, '
+                               f'R={r} rays ({"random pixels" if args.rays else "all pixels"} of a {img_h}x{img_w} target), 64 coarse + 128 fine samples/ray, '
                                'two 247300-param ResNet-MLPs (379->128, 3+3 blocks), explicit uniforms',
                    'rays_per_gpu': b * r, 'samples_per_ray': [s, 2 * s], 'n_views': args.views,
                    'call': 'mvnerf_render_fwd' if args.fused_call else f'op sequence ({8 if use_table else 6} C-ABI launches/step)',
@@ -183,7 +187,7 @@ def main():
                 result['roofline']['frac_reference_equiv'] = result['roofline']['reference_equiv_tflops'] / peak
                 result['roofline']['project_texels_ms_per_step'] = float(np.mean([e[4].elapsed_time(e[5]) for e in ev]))
             pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-            if os.path.exists(pmc) and not bf16 and args.views == 1 and args.size == 64:   # counters were collected on cfg2
+            if os.path.exists(pmc) and not bf16 and args.views == 1 and (img_h, img_w, r) == (64, 64, 4096):   # counters were collected on cfg2
                 try:
                     key = 'field_eval_table_fine_hbm_bytes_per_launch' if use_table else 'field_eval_fine_hbm_bytes_per_launch'
                     result['roofline']['traffic'] = json.load(open(pmc)).get(key)
