@@ -378,32 +378,51 @@ __global__ __launch_bounds__(256) void dir_bias_kernel(FieldParams p) {
 }
 
 // ---- texel table: T[b*V+v][y][x][.] = W0[123:379]^T features[b,v,y,x,:] in accumulator order [h][nb][r] ----
-// One wavefront per (32 texels, output block nb): 32 steps of 4 k-steps; A = feature groups 8..39 of the packed
-// layer-0 kernel (chunk (g, nb)), B = this lane's texel, channels 8q + 4h + {0..3} of group q (one float4).
+// One workgroup per 32 texels, one wavefront per output block nb.  The 32 feature rows (32 KiB) are staged in LDS
+// with coalesced 16-byte loads (XOR-swizzled: the B operand read "lane = texel" is then conflict-free); every wave
+// runs 32 steps of 4 k-steps: A = feature groups 8..39 of the packed layer-0 kernel (chunk (g, nb)), B = channels
+// 8q + 4h + {0..3} of this lane's texel.  Two accumulators alternate so consecutive MFMAs do not depend on each other.
 __global__ __launch_bounds__(256) void project_texels_kernel(const float* __restrict__ features,
                                                              const float* __restrict__ net, long n_texels,
                                                              float* __restrict__ table) {
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int nb = threadIdx.x >> 6;
-    long t = (long)blockIdx.x * 32 + j;
-    const bool valid = t < n_texels;
-    if (!valid) t = n_texels - 1;
-    const f32x4* f = reinterpret_cast<const f32x4*>(features) + t * 64 + h;
-    const f32x4* w = reinterpret_cast<const f32x4*>(net) + ((long)kL0GroupFeat * 4 + nb) * 64 + lane;
-    f32x16 acc;
+    __shared__ __attribute__((aligned(16))) f32x4 srow[32 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int nb = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long t0 = (long)blockIdx.x * 32;
+    const f32x4* fsrc = reinterpret_cast<const f32x4*>(features);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll 8
-    for (int q = 0; q < 32; ++q) {
-        const f32x4 a = w[(long)q * 256], b = f[2 * q];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = mfma(a[e], b[e], acc);
+    for (int m = 0; m < 8; ++m) {
+        const int idx = tid + 256 * m;                      // float4 index inside the 32 x 64 block
+        const int row = idx >> 6, chunk = idx & 63;
+        long t = t0 + row;
+        if (t >= n_texels) t = n_texels - 1;
+        srow[row * 64 + (chunk ^ (row & 15))] = fsrc[t * 64 + chunk];
     }
-    if (valid) {
+    __syncthreads();
+    const f32x4* w = reinterpret_cast<const f32x4*>(net) + ((long)kL0GroupFeat * 4 + nb) * 64 + lane;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc0[r] = 0.0f;
+        acc1[r] = 0.0f;
+    }
+#pragma unroll 4
+    for (int q = 0; q < 32; q += 2) {
+        const f32x4 a0 = w[(long)q * 256], a1 = w[(long)(q + 1) * 256];
+        const f32x4 b0 = srow[j * 64 + ((2 * q + h) ^ (j & 15))], b1 = srow[j * 64 + ((2 * q + 2 + h) ^ (j & 15))];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc0 = mfma(a0[e], b0[e], acc0);
+            acc1 = mfma(a1[e], b1[e], acc1);
+        }
+    }
+    const long t = t0 + j;
+    if (t < n_texels) {
         f32x4* out = reinterpret_cast<f32x4*>(table + 128 * t + 64 * h + 16 * nb);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            const f32x4 v = {acc0[4 * q] + acc1[4 * q], acc0[4 * q + 1] + acc1[4 * q + 1], acc0[4 * q + 2] + acc1[4 * q + 2],
+                             acc0[4 * q + 3] + acc1[4 * q + 3]};
             out[q] = v;
         }
     }
