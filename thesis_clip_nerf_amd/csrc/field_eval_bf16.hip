@@ -87,6 +87,12 @@ hipError_t launch_pack_net_bf16(const float* net_keras, void* packed16, hipStrea
 #ifndef MV16_PIPE_A
 #define MV16_PIPE_A 1      // A operands of k-step ks+1 requested before the MFMAs of ks (0: compiler-scheduled)
 #endif
+#ifndef MV16_ABL_AREUSE
+#define MV16_ABL_AREUSE 0  // timing-only: one LDS read per k-step instead of four (same A for all output blocks)
+#endif
+#ifndef MV16_ABL_CVT
+#define MV16_ABL_CVT 0     // timing-only: no relu / bf16 conversion of the hidden-layer B operands
+#endif
 #ifndef MV16_ABL_DMA
 #define MV16_ABL_DMA 0     // timing-only ablations (wrong results): no weight DMA after the prologue
 #endif
@@ -204,14 +210,14 @@ __device__ __forceinline__ void segment_mfma(Ring& ring, int lane, BFn bfn, f32x
 #endif
     f32x4 a[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) a[nb] = wb[nb * 64];
+    for (int nb = 0; nb < 4; ++nb) a[nb] = wb[(MV16_ABL_AREUSE ? 0 : nb) * 64];
     bf16x8 b = bfn(0);
 #pragma unroll
     for (int ks = 0; ks < kKs; ++ks) {
         f32x4 an[4];
         if (ks < kKs - 1) {
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) an[nb] = wb[((ks + 1) * 4 + nb) * 64];
+            for (int nb = 0; nb < 4; ++nb) an[nb] = wb[((ks + 1) * 4 + (MV16_ABL_AREUSE ? 0 : nb)) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -228,7 +234,14 @@ __device__ __forceinline__ void segment_mfma(Ring& ring, int lane, BFn bfn, f32x
 __device__ __forceinline__ void dense128_bf16(Ring& ring, int lane, const f32x16 (&in)[4], f32x16 (&acc)[4]) {
 #pragma unroll
     for (int seg = 0; seg < 8 / kKs; ++seg) {
-        segment_mfma(ring, lane, [&](int ks) { const int g = seg * kKs + ks; return relu_to_bf16(in[g >> 1], g & 1); }, acc);
+        segment_mfma(ring, lane, [&](int ks) {
+            const int g = seg * kKs + ks;
+            if (MV16_ABL_CVT) {
+                const f32x4 raw = {in[g >> 1][8 * (g & 1)], in[g >> 1][8 * (g & 1) + 1], in[g >> 1][8 * (g & 1) + 2], in[g >> 1][8 * (g & 1) + 3]};
+                return __builtin_bit_cast(bf16x8, raw);
+            }
+            return relu_to_bf16(in[g >> 1], g & 1);
+        }, acc);
         ring_next<false>(ring);
     }
 }
