@@ -333,21 +333,7 @@ int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const floa
 int mvnerf_pack_bwd_streams(const float* net_keras, float* bwd_streams, mvnerf_stream_t stream) {
     if (!net_keras || !bwd_streams) return fail(MVNERF_E_ARG, "mvnerf_pack_bwd_streams: null pointer");
     if (!aligned16(bwd_streams)) return fail(MVNERF_E_ALIGN, "mvnerf_pack_bwd_streams: bwd_streams must be 16-byte aligned");
-    for (int l = 0; l < 12; ++l) {
-        const float* src = net_keras + mvnerf::kKerasBlocks + (l / 2) * mvnerf::kKerasBlockStride +
-                           (l % 2) * (mvnerf::kHidden * mvnerf::kHidden + mvnerf::kHidden);
-        const hipError_t e = mvnerf::launch_pack_dense(src, 1, 128, bwd_streams + (size_t)l * mvnerf::kHiddenWFloats,
-                                                       static_cast<hipStream_t>(stream));
-        if (e != hipSuccess) return hip_status(e, "mvnerf_pack_bwd_streams");
-    }
-    for (int slab = 0; slab < 3; ++slab) {            // layer-0 kernel rows [128 slab, 128 slab + 128), transposed
-        const int valid = mvnerf::kIn - 128 * slab < 128 ? mvnerf::kIn - 128 * slab : 128;
-        const hipError_t e = mvnerf::launch_pack_dense(net_keras + mvnerf::kKerasW0 + (size_t)slab * 128 * mvnerf::kHidden, 1, valid,
-                                                       bwd_streams + (size_t)(12 + slab) * mvnerf::kHiddenWFloats,
-                                                       static_cast<hipStream_t>(stream));
-        if (e != hipSuccess) return hip_status(e, "mvnerf_pack_bwd_streams");
-    }
-    return 0;
+    return hip_status(mvnerf::launch_pack_bwd_streams(net_keras, bwd_streams, static_cast<hipStream_t>(stream)), "mvnerf_pack_bwd_streams");
 }
 
 int mvnerf_mse_grad(const float* pred, const float* label, long n, float* d_pred, float* loss, mvnerf_stream_t stream) {

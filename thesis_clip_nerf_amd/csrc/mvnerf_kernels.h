@@ -75,7 +75,7 @@ hipError_t launch_finish_view(const float* rgb, const float* depth, long n, floa
                               hipStream_t st);
 
 // train_ops.hip
-hipError_t launch_pack_dense(const float* src, int transpose, int valid_rows, float* dst, hipStream_t st);
+hipError_t launch_pack_bwd_streams(const float* net_keras, float* dst, hipStream_t st);
 hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, float* d_o,
                            float* d_d, float* d_features, hipStream_t st);
 hipError_t launch_rows_to_tl(const float* rows, long n_rows, long n_tiles, int accumulate, float* out_tl, hipStream_t st);

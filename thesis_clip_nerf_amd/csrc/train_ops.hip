@@ -22,23 +22,35 @@
 namespace mvnerf {
 
 // ---- weight images for the backward GEMMs -------------------------------------------------------------
-// src: one Keras Dense kernel [128][128] (in, out).  dst: 16384 floats in hidden-layer stream order
-// (mvnerf_pack.h) of M = src (transpose = 0) or M = src^T (transpose = 1), M indexed [k_in][n_out].
-// valid_rows: rows of src that exist (a 128-row slab of the 379-row layer-0 kernel may be shorter); the rest is 0.
-__global__ void pack_dense_kernel(const float* __restrict__ src, int transpose, int valid_rows, float* __restrict__ dst) {
+// One Keras Dense kernel [128][128] (in, out) -> 16384 floats in hidden-layer stream order (mvnerf_pack.h) of its
+// transpose M = src^T, M indexed [k_in][n_out]; rows of src that do not exist (the last slab of the 379-row layer-0
+// kernel is shorter) give zeros.
+// All 15 transposed streams of one MLP in one launch (blockIdx.y = stream): the 12 hidden kernels, then the three
+// 128-row slabs of the 379-row layer-0 kernel.
+__global__ void pack_bwd_streams_kernel(const float* __restrict__ net_keras, float* __restrict__ dst) {
+    const int l = blockIdx.y;
+    const float* src;
+    int valid = 128;
+    if (l < 12) {
+        src = net_keras + kKerasBlocks + (l / 2) * kKerasBlockStride + (l % 2) * (kHidden * kHidden + kHidden);
+    } else {
+        const int slab = l - 12;
+        src = net_keras + kKerasW0 + (long)slab * 128 * kHidden;
+        valid = kIn - 128 * slab < 128 ? kIn - 128 * slab : 128;
+    }
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= kHiddenWFloats) return;
     const int e = idx % 4, lane = (idx % kChunkFloats) / 4, i = lane & 31, h = lane >> 5;
     const int grp = idx / kGroupFloats, nb = (idx % kGroupFloats) / kChunkFloats;
     const int k = 32 * (grp / 4) + 8 * (grp % 4) + 4 * h + e, n = 32 * nb + i;
-    const int row = transpose ? n : k;
-    dst[idx] = row < valid_rows ? (transpose ? src[n * kHidden + k] : src[k * kHidden + n]) : 0.0f;
+    dst[(long)l * kHiddenWFloats + idx] = n < valid ? src[n * kHidden + k] : 0.0f;      // M = src^T, rows of src beyond `valid` are 0
 }
 
-hipError_t launch_pack_dense(const float* src, int transpose, int valid_rows, float* dst, hipStream_t st) {
-    hipLaunchKernelGGL(pack_dense_kernel, dim3(kHiddenWFloats / 256), dim3(256), 0, st, src, transpose, valid_rows, dst);
+hipError_t launch_pack_bwd_streams(const float* net_keras, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(pack_bwd_streams_kernel, dim3(kHiddenWFloats / 256, 15), dim3(256), 0, st, net_keras, dst);
     return hipGetLastError();
 }
+
 
 // ---- dW[k][n] += sum_rows relu(a)[k] g[n] ; db[n] += sum_rows g[n] -----------------------------------------
 // a_tl: (rows,128) pre-activations in TL (relu applied on load when relu_a); g_tl: (rows, 32*kNB) in TL.
