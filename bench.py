@@ -143,12 +143,14 @@ def main():
     value = rays_per_step * args.steps / elapsed
 
     result = {
-        'metric': 'rendered_rays_per_sec', 'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
+        'metric': 'rendered rays/sec (64 samples/ray)', 'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': f'cfg2: _call on B=1 scene/GPU, V={args.views} source view {img_h}x{img_w}x(3+256) fp32, '
                                f'R={r} rays ({"random pixels" if args.rays else "all pixels"} of a {img_h}x{img_w} target), 64 coarse + 128 fine samples/ray, '
                                'two 247300-param ResNet-MLPs (379->128, 3+3 blocks), explicit uniforms',
+                   'ray_definition': 'one full _call row: 64 stratified coarse samples + 128 merged fine samples through both MLPs '
+                                     '(the conservative reading; the coarse pass alone is roofline.coarse_only_rays_per_sec)',
                    'rays_per_gpu': b * r, 'samples_per_ray': [s, 2 * s], 'n_views': args.views,
                    'call': 'mvnerf_render_fwd' if args.fused_call else f'op sequence ({8 if use_table else 6} C-ABI launches/step)',
                    'layer0_features': 'texel table, rebuilt every step' if use_table else 'gathered per sample',
