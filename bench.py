@@ -192,7 +192,11 @@ def main():
             if os.path.exists(pmc) and not bf16 and args.views == 1 and (img_h, img_w, r) == (64, 64, 4096):   # counters were collected on cfg2
                 try:
                     key = 'field_eval_table_fine_hbm_bytes_per_launch' if use_table else 'field_eval_fine_hbm_bytes_per_launch'
-                    result['roofline']['traffic'] = json.load(open(pmc)).get(key)
+                    counters = json.load(open(pmc))
+                    result['roofline']['traffic'] = counters.get(key)
+                    if counters.get(key):                  # rocprof counters (profiles/): HBM-side GB/s of this launch, matrix pipe busy
+                        result['roofline']['hbm_gbps_from_pmc_traffic'] = counters[key] / (fine_ms * 1e-3) / 1e9
+                        result['roofline']['mfma_busy_pmc'] = counters.get(key.replace('hbm_bytes_per_launch', 'mfma_busy'))
                 except Exception:
                     pass
         if world == 1 and args.train_steps > 0 and not bf16:
