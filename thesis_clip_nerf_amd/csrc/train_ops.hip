@@ -192,6 +192,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         __syncthreads();
+        // the residual rows of this wave's output block are requested now and consumed in the epilogue: asked for there
+        // (behind the scheduling fences of the MFMA sections) their latency would be exposed once per tile
+        float rs[16];
+        const long obase = tl_index(tile, 128, 32 * w + 4 * h, j);           // row 32w + 4h (+ (r&3) + 8(r>>2))
+        if (resid_tl) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rs[r] = resid_tl[obase + ((r & 3) + 8 * (r >> 2)) * 32];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rs[r] = 0.0f;
+        }
         // ---- dL/da rows of block w: out[32w + i'][j] = sum_n M[n][32w + i'] G[n][j] ----
         f32x16 acc;
 #pragma unroll
@@ -244,15 +255,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         }
         // ---- epilogue of dL/da: relu mask from the staged a tile, optional residual, store ----
-        float rs[16];
-        const long obase = tl_index(tile, 128, 32 * w + 4 * h, j);           // row 32w + 4h (+ (r&3) + 8(r>>2))
-        if (resid_tl) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rs[r] = resid_tl[obase + ((r & 3) + 8 * (r >> 2)) * 32];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rs[r] = 0.0f;
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float av = reinterpret_cast<const float*>(sA)[ebase[r & 3] + 8 * (r >> 2) * 32];
