@@ -203,11 +203,13 @@ size_t mvnerf_stash_bytes(int B, int V, int R, int S);
 /* Bytes of scratch mvnerf_field_backward needs. */
 size_t mvnerf_field_backward_scratch_bytes(int B, int V, int R, int S);
 
-/* mvnerf_field_eval in training mode: also stores the trunk's pre-activations into `stash`. */
+/* mvnerf_field_eval in training mode: also stores the trunk's pre-activations into `stash`.
+ * texel_table (optional, may be NULL): as in mvnerf_field_eval_table, for the forward value only - the backward
+ * recomputes layer 0's inputs from the raw features either way. */
 int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const float* z, const float* images,
-                            const float* features, const float* intrinsics, const float* extrinsics_inv,
-                            const float* packed_net, int B, int V, int R, int S, int H, int W, float* rgbs, float* stash,
-                            void* workspace, mvnerf_stream_t stream);
+                            const float* features, const float* texel_table, const float* intrinsics,
+                            const float* extrinsics_inv, const float* packed_net, int B, int V, int R, int S, int H, int W,
+                            float* rgbs, float* stash, void* workspace, mvnerf_stream_t stream);
 
 /* The 12 hidden Dense kernels of one MLP and the three 128-row slabs of the layer-0 kernel, transposed, in
  * weight-stream order (15 x 16384 floats), for the dX GEMMs of the backward pass.

@@ -303,9 +303,10 @@ size_t mvnerf_field_backward_scratch_bytes(int B, int V, int R, int S) {
 }
 
 int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const float* z, const float* images,
-                            const float* features, const float* intrinsics, const float* extrinsics_inv,
-                            const float* packed_net, int B, int V, int R, int S, int H, int W, float* rgbs, float* stash,
-                            void* workspace, mvnerf_stream_t stream) {
+                            const float* features, const float* texel_table, const float* intrinsics,
+                            const float* extrinsics_inv, const float* packed_net, int B, int V, int R, int S, int H, int W,
+                            float* rgbs, float* stash, void* workspace, mvnerf_stream_t stream) {
+    if (texel_table && !aligned16(texel_table)) return fail(MVNERF_E_ALIGN, "mvnerf_field_eval_stash: texel_table must be 16-byte aligned");
     if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !packed_net || !rgbs || !stash || !workspace)
         return fail(MVNERF_E_ARG, "mvnerf_field_eval_stash: null pointer");
     if (B <= 0 || V <= 0 || R <= 0 || S <= 0 || H < 2 || W < 2) return fail(MVNERF_E_ARG, "mvnerf_field_eval_stash: B=%d V=%d R=%d S=%d H=%d W=%d", B, V, R, S, H, W);
@@ -319,6 +320,7 @@ int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const floa
     mvnerf::FieldParams p = {};
     p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.images = images; p.features = features;
     p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs;
+    p.texel_table = texel_table;
     p.dir_bias = static_cast<float*>(workspace);
     p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W;
     p.total = total;

@@ -535,9 +535,11 @@ hipError_t launch_field_eval(const FieldParams& p_in, hipStream_t stream) {
                 {reinterpret_cast<const void*>(&field_eval_kernel<false, false, false>), lds_sv},
                 {reinterpret_cast<const void*>(&field_eval_kernel<false, false, true>), lds_sv},
                 {reinterpret_cast<const void*>(&field_eval_kernel<false, true, false>), lds_sv},
+                {reinterpret_cast<const void*>(&field_eval_kernel<false, true, true>), lds_sv},
                 {reinterpret_cast<const void*>(&field_eval_kernel<true, false, false>), lds_mv},
                 {reinterpret_cast<const void*>(&field_eval_kernel<true, false, true>), lds_mv},
                 {reinterpret_cast<const void*>(&field_eval_kernel<true, true, false>), lds_mv},
+                {reinterpret_cast<const void*>(&field_eval_kernel<true, true, true>), lds_mv},
             };
             for (const auto& k : kernels)
                 if ((e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes)) != hipSuccess) return e;
@@ -556,18 +558,19 @@ hipError_t launch_field_eval(const FieldParams& p_in, hipStream_t stream) {
     const long resident = (long)di.cus * (p.V > 1 ? 1 : 8 / MV_WAVES);   // workgroups that fit at once
     const unsigned wgs = (unsigned)((MV_PERSIST && want > resident) ? resident : want);
     const size_t lds_bytes = (size_t)waves * kTile * kStageRow * 4;
-    if (p.stash && p.texel_table) return hipErrorInvalidValue;           // the training kernels gather raw features
     if (p.V > 1) {
         if (p.stash) {
             if (((long)p.R * p.S) % 32 != 0) return hipErrorInvalidValue;     // tiles must not straddle scenes
-            hipLaunchKernelGGL((field_eval_kernel<true, true, false>), dim3(wgs), dim3(256), lds_bytes, stream, p);
+            if (p.texel_table) hipLaunchKernelGGL((field_eval_kernel<true, true, true>), dim3(wgs), dim3(256), lds_bytes, stream, p);
+            else hipLaunchKernelGGL((field_eval_kernel<true, true, false>), dim3(wgs), dim3(256), lds_bytes, stream, p);
         } else if (p.texel_table) {
             hipLaunchKernelGGL((field_eval_kernel<true, false, true>), dim3(wgs), dim3(256), lds_bytes, stream, p);
         } else {
             hipLaunchKernelGGL((field_eval_kernel<true, false, false>), dim3(wgs), dim3(256), lds_bytes, stream, p);
         }
     } else if (p.stash) {
-        hipLaunchKernelGGL((field_eval_kernel<false, true, false>), dim3(wgs), dim3(64 * MV_WAVES), lds_bytes, stream, p);
+        if (p.texel_table) hipLaunchKernelGGL((field_eval_kernel<false, true, true>), dim3(wgs), dim3(64 * MV_WAVES), lds_bytes, stream, p);
+        else hipLaunchKernelGGL((field_eval_kernel<false, true, false>), dim3(wgs), dim3(64 * MV_WAVES), lds_bytes, stream, p);
     } else if (p.texel_table) {
         hipLaunchKernelGGL((field_eval_kernel<false, false, true>), dim3(wgs), dim3(64 * MV_WAVES), lds_bytes, stream, p);
     } else {

@@ -219,11 +219,17 @@ class MVVNeRFRenderer:
             self._packed_bwd = (ops.pack_bwd_streams(self.coarse_net), ops.pack_bwd_streams(self.fine_net))
         geo = (images, feats, k4, einv)
         # forward, keeping the trunk pre-activations
+        tab_c = tab_f = None
+        if ops.texel_table_pays(r, self.n_samples, images.shape[2], images.shape[3]):      # forward value only (section 4.1b)
+            if tb.get('tables') is None or tuple(tb['tables'].shape[1:]) != tuple(feats.shape[:4]) + (128,):
+                tb['tables'] = torch.empty((2,) + tuple(feats.shape[:4]) + (128,), dtype=torch.float32, device=self.device)
+            tab_c = ops.project_texels(feats, pc, out=tb['tables'][0])
+            tab_f = ops.project_texels(feats, pf, out=tb['tables'][1])
         z = ops.stratified_depths(self._dev(u_coarse), self.near, self.far)
-        rgbs_c, tb['stash_c'] = ops.field_eval_stash(rays_o, rays_d, z, *geo, pc, tb.get('stash_c'))
+        rgbs_c, tb['stash_c'] = ops.field_eval_stash(rays_o, rays_d, z, *geo, pc, tb.get('stash_c'), texel_table=tab_c)
         rgb, depth, w = ops.composite(z, rgbs_c)
         z_all, rank = ops.resample(z, w, self._dev(u_fine), self.q7_mode, return_rank=True)
-        rgbs_f, tb['stash_f'] = ops.field_eval_stash(rays_o, rays_d, z_all, *geo, pf, tb.get('stash_f'))
+        rgbs_f, tb['stash_f'] = ops.field_eval_stash(rays_o, rays_d, z_all, *geo, pf, tb.get('stash_f'), texel_table=tab_f)
         fine_rgb, fine_depth, _ = ops.composite(z_all, rgbs_f, return_weights=False)
         # loss and its gradient w.r.t. the two rendered images
         loss = torch.zeros(1, dtype=torch.float32, device=self.device)

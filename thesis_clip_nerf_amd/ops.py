@@ -407,7 +407,7 @@ def stash_bytes(b, v, r, s):
     return int(_lib.lib().mvnerf_stash_bytes(int(b), int(v), int(r), int(s)))
 
 
-def field_eval_stash(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, stash=None):
+def field_eval_stash(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, stash=None, texel_table=None):
     """Training-mode field pass: -> (rgbs (B,R,S,4), stash uint8 tensor with the trunk pre-activations)."""
     _chk(rays_o, 'rays_o', shape=(None, None, 3))
     b, r, _ = rays_o.shape
@@ -427,9 +427,11 @@ def field_eval_stash(rays_o, rays_d, z, images, features, intrinsics, extrinsics
     rgbs = torch.empty((b, r, s, 4), dtype=torch.float32, device=dev)
     ws = torch.empty(int(_lib.lib().mvnerf_field_workspace_bytes(b, v, r)), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        rc = _lib.lib().mvnerf_field_eval_stash(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(intrinsics),
-                                                _p(extrinsics_inv), _p(packed_net), b, v, r, s, h, w, _p(rgbs), _p(stash),
-                                                _p(ws), _stream(rays_o))
+        if texel_table is not None:
+            _chk(texel_table, 'texel_table', shape=(b, v, h, w, 128))
+        rc = _lib.lib().mvnerf_field_eval_stash(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(texel_table),
+                                                _p(intrinsics), _p(extrinsics_inv), _p(packed_net), b, v, r, s, h, w, _p(rgbs),
+                                                _p(stash), _p(ws), _stream(rays_o))
     _lib.check(rc, 'field_eval_stash')
     return rgbs, stash
 
