@@ -106,8 +106,12 @@ def main():
         tab_c = tab_f = None
         if e: e[4].record()
         if use_table:                      # inside the step: a new _call brings new feature maps
-            tab_c = ops.project_texels(t['features'], pc, out=tables[0])
-            tab_f = ops.project_texels(t['features'], pf, out=tables[1])
+            if bf16:
+                tab_c = ops.project_texels_bf16(t['features'], pc16, out=tables[0])
+                tab_f = ops.project_texels_bf16(t['features'], pf16, out=tables[1])
+            else:
+                tab_c = ops.project_texels(t['features'], pc, out=tables[0])
+                tab_f = ops.project_texels(t['features'], pf, out=tables[1])
         if e: e[5].record()
         z = ops.stratified_depths(t['u_coarse'], near, far)
         if e: e[0].record()

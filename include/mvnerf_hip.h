@@ -120,6 +120,10 @@ int mvnerf_field_eval_table(const float* rays_o, const float* rays_d, const floa
 size_t mvnerf_packed_net_bf16_bytes(void);
 /* Keras-order fp32 MLP (see mvnerf_pack_net) -> bf16 MFMA operand stream.  packed16: 16-byte aligned. */
 int mvnerf_pack_net_bf16(const float* net_keras, void* packed16, mvnerf_stream_t stream);
+/* mvnerf_project_texels on the bf16 MFMA: features and W0's feature rows rounded to bf16, fp32 accumulation, fp32 table
+ * (same layout) - for mvnerf_field_eval_bf16(texel_table = ...); 16x less matrix time than the fp32 projection. */
+int mvnerf_project_texels_bf16(const float* features, const void* packed16, int B, int V, int H, int W, float* texel_table,
+                               mvnerf_stream_t stream);
 /* As mvnerf_field_eval, with the Dense kernels taken from packed16 (biases and the per-ray layer-0 seed still come
  * from the fp32 image packed_net).  Optional outputs: tap_idx, embedding, acts_fused (4,B,R,S,128) = the view mean and
  * the three fusion blocks (the part of complete_output that LanguageNeRF consumes, lmvnerf/model_v4.py:261).

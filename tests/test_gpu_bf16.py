@@ -119,3 +119,15 @@ def test_bf16_texel_table_close_to_direct():
     e_tab = (tab - ref).abs().mean().item()
     assert e_tab < 1.2 * e_direct + 1e-6, (e_tab, e_direct)
     assert (tab - ref).abs().max().item() < 2e-2
+
+
+def test_project_texels_bf16_close_to_fp32_table():
+    sc = make_scene(seed=13, n_views=2, height=10, width=14, n_rays=4)
+    feats = torch.from_numpy(np.ascontiguousarray(sc['features'])).to(DEV)
+    net = torch.from_numpy(np.ascontiguousarray(sc['fine'])).to(DEV)
+    t32 = ops.project_texels(feats, ops.pack_net(net))
+    t16 = ops.project_texels_bf16(feats, ops.pack_net_bf16(net))
+    torch.cuda.synchronize()
+    assert t16.shape == t32.shape
+    err = (t16 - t32).abs()
+    assert err.mean().item() < 4e-3 * t32.abs().mean().item() and err.max().item() < 3e-2 * t32.abs().max().item()

@@ -36,6 +36,7 @@ SIGNATURES = {
     'mvnerf_project_texels': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
     'mvnerf_field_eval_table': (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_void_p] * 8),
     'mvnerf_packed_net_bf16_bytes': (c_size_t, []),
+    'mvnerf_project_texels_bf16': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
     'mvnerf_pack_net_bf16': (c_int, [c_void_p, c_void_p, c_void_p]),
     'mvnerf_field_eval_bf16': (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_void_p] * 6),
     'mvnerf_field_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

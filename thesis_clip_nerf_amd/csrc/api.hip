@@ -155,6 +155,18 @@ int mvnerf_pack_net_bf16(const float* net_keras, void* packed16, mvnerf_stream_t
     return hip_status(mvnerf::launch_pack_net_bf16(net_keras, packed16, static_cast<hipStream_t>(stream)), "mvnerf_pack_net_bf16");
 }
 
+int mvnerf_project_texels_bf16(const float* features, const void* packed16, int B, int V, int H, int W, float* texel_table,
+                               mvnerf_stream_t stream) {
+    if (!features || !packed16 || !texel_table) return fail(MVNERF_E_ARG, "mvnerf_project_texels_bf16: null pointer");
+    if (B <= 0 || V <= 0 || H < 2 || W < 2) return fail(MVNERF_E_ARG, "mvnerf_project_texels_bf16: B=%d V=%d H=%d W=%d", B, V, H, W);
+    if ((long)B * V * H * W >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_project_texels_bf16: B*V*H*W too large for int32 indices");
+    if (!aligned16(features) || !aligned16(packed16) || !aligned16(texel_table))
+        return fail(MVNERF_E_ALIGN, "mvnerf_project_texels_bf16: features, packed16, texel_table must be 16-byte aligned");
+    return hip_status(mvnerf::launch_project_texels_bf16(features, packed16, (long)B * V * H * W, texel_table,
+                                                         static_cast<hipStream_t>(stream)),
+                      "mvnerf_project_texels_bf16");
+}
+
 int mvnerf_field_eval_bf16(const float* rays_o, const float* rays_d, const float* z, const float* images,
                            const float* features, const float* texel_table, const float* intrinsics, const float* extrinsics_inv,
                            const float* packed_net, const void* packed16, int B, int V, int R, int S, int H, int W,

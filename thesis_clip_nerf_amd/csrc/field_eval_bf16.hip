@@ -165,6 +165,63 @@ __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// ---- texel table on the bf16 MFMA (see field_eval.hip, project_texels_kernel, for the fp32 form) --------------
+// T[texel] = W0[123:379]^T features[texel] with bf16 inputs and fp32 accumulation - the same rounding the direct bf16
+// kernel applies to the gathered features, 16x less matrix time than the fp32 projection (which dominates the bf16
+// path on many-texel scenes).  One workgroup per 32 texels: the rows are staged in LDS as bf16 (coalesced fp32 loads,
+// XOR-swizzled 16-byte chunks), wave nb runs the 16 feature k-steps of output block nb on two alternating accumulators.
+__global__ __launch_bounds__(256) void project_texels_bf16_kernel(const float* __restrict__ features, const f32x4* __restrict__ w16,
+                                                                  long n_texels, float* __restrict__ table) {
+    __shared__ __attribute__((aligned(16))) unsigned char srow[32 * 512];          // 32 texels x 256 channels x bf16
+    using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int nb = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long t0 = (long)blockIdx.x * 32;
+    const f32x4* fsrc = reinterpret_cast<const f32x4*>(features);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int idx = tid + 256 * m;                      // float4 index inside the 32 x 64 block
+        const int row = idx >> 6, c4 = idx & 63;            // channels 4 c4 .. 4 c4 + 3
+        long t = t0 + row;
+        if (t >= n_texels) t = n_texels - 1;
+        const f32x4 v = fsrc[t * 64 + c4];
+        const int chunk = c4 >> 1;                          // 16-byte chunk of 8 channels
+        *reinterpret_cast<bf16x4*>(srow + row * 512 + ((chunk ^ (row & 15)) << 4) + ((c4 & 1) << 3)) = __builtin_convertvector(v, bf16x4);
+    }
+    __syncthreads();
+    const f32x4* w = w16 + ((long)16 + nb) * 64 + lane;    // chunk (k-step 4 + ks, nb) = 4 (4 + ks) + nb
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc0[r] = 0.0f;
+        acc1[r] = 0.0f;
+    }
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ks += 2) {
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, w[(long)ks * 256]), a1 = __builtin_bit_cast(bf16x8, w[(long)(ks + 1) * 256]);
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(srow + j * 512 + (((2 * ks + h) ^ (j & 15)) << 4));
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(srow + j * 512 + (((2 * ks + 2 + h) ^ (j & 15)) << 4));
+        acc0 = mfma16(a0, b0, acc0);
+        acc1 = mfma16(a1, b1, acc1);
+    }
+    const long t = t0 + j;
+    if (t < n_texels) {
+        f32x4* out = reinterpret_cast<f32x4*>(table + 128 * t + 64 * h + 16 * nb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc0[4 * q] + acc1[4 * q], acc0[4 * q + 1] + acc1[4 * q + 1], acc0[4 * q + 2] + acc1[4 * q + 2],
+                             acc0[4 * q + 3] + acc1[4 * q + 3]};
+            out[q] = v;
+        }
+    }
+}
+
+hipError_t launch_project_texels_bf16(const float* features, const void* packed16, long n_texels, float* table, hipStream_t stream) {
+    hipLaunchKernelGGL(project_texels_bf16_kernel, dim3((unsigned)((n_texels + 31) / 32)), dim3(256), 0, stream, features,
+                       static_cast<const f32x4*>(packed16), n_texels, table);
+    return hipGetLastError();
+}
+
 // one k-step (16 input rows) x 4 output blocks out of the LDS-resident segment
 __device__ __forceinline__ void step16(const f32x4* wbuf, int ks_local, int lane, bf16x8 b, f32x16 (&acc)[4]) {
 #pragma unroll

@@ -525,6 +525,21 @@ def pack_net_bf16(net_keras):
     return out
 
 
+def project_texels_bf16(features, packed16, out=None):
+    """mvnerf_project_texels_bf16: the texel table of one net on the bf16 MFMA (fp32 table, same layout as project_texels)."""
+    _chk(features, 'features', shape=(None, None, None, None, 256))
+    b, v, h, w, _ = features.shape
+    _chk(packed16, 'packed16', dtype=torch.uint8, shape=(int(_lib.lib().mvnerf_packed_net_bf16_bytes()),))
+    if out is None:
+        out = torch.empty((b, v, h, w, 128), dtype=torch.float32, device=features.device)
+    else:
+        _chk(out, 'texel_table', shape=(b, v, h, w, 128))
+    with torch.cuda.device(features.device):
+        rc = _lib.lib().mvnerf_project_texels_bf16(_p(features), _p(packed16), b, v, h, w, _p(out), _stream(features))
+    _lib.check(rc, 'project_texels_bf16')
+    return out
+
+
 def field_eval_bf16(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, packed16, return_taps=False,
                     return_embedding=False, return_fused_acts=False, texel_table=None):
     """mvnerf_field_eval_bf16: as field_eval with the Dense layers on the bf16 MFMA path.
@@ -570,8 +585,8 @@ def render_fwd_bf16(rays_o, rays_d, images, features, intrinsics, extrinsics_inv
         texel_tables = (torch.empty((2,) + tuple(features.shape[:4]) + (128,), dtype=torch.float32, device=features.device)
                         if texel_table_pays(r, s, h, w_) else None)
     if texel_tables is not None:
-        tab_c = project_texels(features, packed_coarse, out=texel_tables[0])
-        tab_f = project_texels(features, packed_fine, out=texel_tables[1])
+        tab_c = project_texels_bf16(features, packed16_coarse, out=texel_tables[0])
+        tab_f = project_texels_bf16(features, packed16_fine, out=texel_tables[1])
     z = stratified_depths(u_coarse, near, far)
     rgbs_c = field_eval_bf16(rays_o, rays_d, z, *geo, packed_coarse, packed16_coarse, texel_table=tab_c)
     rgb, depth, w = composite(z, rgbs_c)
