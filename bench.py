@@ -107,11 +107,9 @@ def main():
         if e: e[4].record()
         if use_table:                      # inside the step: a new _call brings new feature maps
             if bf16:
-                tab_c = ops.project_texels_bf16(t['features'], pc16, out=tables[0])
-                tab_f = ops.project_texels_bf16(t['features'], pf16, out=tables[1])
+                tab_c, tab_f = ops.project_texels_bf16(t['features'], pc16, out=tables, packed16_b=pf16).unbind(0)
             else:
-                tab_c = ops.project_texels(t['features'], pc, out=tables[0])
-                tab_f = ops.project_texels(t['features'], pf, out=tables[1])
+                tab_c, tab_f = ops.project_texels2(t['features'], pc, pf, out=tables).unbind(0)
         if e: e[5].record()
         z = ops.stratified_depths(t['u_coarse'], near, far)
         if e: e[0].record()
@@ -156,7 +154,7 @@ def main():
                    'ray_definition': 'one full _call row: 64 stratified coarse samples + 128 merged fine samples through both MLPs '
                                      '(the conservative reading; the coarse pass alone is roofline.coarse_only_rays_per_sec)',
                    'rays_per_gpu': b * r, 'samples_per_ray': [s, 2 * s], 'n_views': args.views,
-                   'call': 'mvnerf_render_fwd' if args.fused_call else f'op sequence ({8 if use_table else 6} C-ABI launches/step)',
+                   'call': 'mvnerf_render_fwd' if args.fused_call else f'op sequence ({7 if use_table else 6} C-ABI calls/step)',
                    'layer0_features': 'texel table, rebuilt every step' if use_table else 'gathered per sample',
                    'parallelism': f'ray/scene sharding x{world}, no data-path collective'},
     }

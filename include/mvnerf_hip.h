@@ -108,6 +108,9 @@ size_t mvnerf_field_workspace_bytes(int B, int V, int R);
 size_t mvnerf_texel_table_bytes(int B, int V, int H, int W);
 int mvnerf_project_texels(const float* features, const float* packed_net, int B, int V, int H, int W, float* texel_table,
                           mvnerf_stream_t stream);
+/* Two nets (coarse, fine) from ONE read of the feature maps; packed_net_b / texel_table_b may both be NULL. */
+int mvnerf_project_texels2(const float* features, const float* packed_net, const float* packed_net_b, int B, int V, int H, int W,
+                           float* texel_table, float* texel_table_b, mvnerf_stream_t stream);
 int mvnerf_field_eval_table(const float* rays_o, const float* rays_d, const float* z, const float* images,
                             const float* features, const float* texel_table, const float* intrinsics,
                             const float* extrinsics_inv, const float* packed_net, int B, int V, int R, int S, int H, int W,
@@ -122,8 +125,8 @@ size_t mvnerf_packed_net_bf16_bytes(void);
 int mvnerf_pack_net_bf16(const float* net_keras, void* packed16, mvnerf_stream_t stream);
 /* mvnerf_project_texels on the bf16 MFMA: features and W0's feature rows rounded to bf16, fp32 accumulation, fp32 table
  * (same layout) - for mvnerf_field_eval_bf16(texel_table = ...); 16x less matrix time than the fp32 projection. */
-int mvnerf_project_texels_bf16(const float* features, const void* packed16, int B, int V, int H, int W, float* texel_table,
-                               mvnerf_stream_t stream);
+int mvnerf_project_texels_bf16(const float* features, const void* packed16, const void* packed16_b, int B, int V, int H, int W,
+                               float* texel_table, float* texel_table_b, mvnerf_stream_t stream);   /* _b: optional second net */
 /* As mvnerf_field_eval, with the Dense kernels taken from packed16 (biases and the per-ray layer-0 seed still come
  * from the fp32 image packed_net).  Optional outputs: tap_idx, embedding, acts_fused (4,B,R,S,128) = the view mean and
  * the three fusion blocks (the part of complete_output that LanguageNeRF consumes, lmvnerf/model_v4.py:261).

@@ -54,6 +54,8 @@ def test_argument_validation_of_table_and_query_entry_points():
     assert lib.mvnerf_project_texels(one, one, 1, 1, 8, 8, None, None) == -1                     # no table
     assert lib.mvnerf_project_texels(one, one, 1, 1, 1, 8, one, None) == -1                      # H < 2
     assert lib.mvnerf_project_texels(one, one, 1, 1, 8, 8, odd, None) == -3                      # misaligned table
+    assert lib.mvnerf_project_texels2(one, one, one, 1, 1, 8, 8, one, None, None) == -1          # second net without its table
+    assert lib.mvnerf_project_texels_bf16(one, one, None, 1, 1, 8, 8, one, one, None) == -1      # second table without its net
     fe_tail = [one, None, None, None, None, None, one, None]
     assert lib.mvnerf_field_eval_table(one, one, one, one, one, None, one, one, one, 1, 1, 4, 64, 8, 8, *fe_tail) == -1   # null table
     assert b'texel_table' in lib.mvnerf_last_error()

@@ -129,5 +129,7 @@ def test_project_texels_bf16_close_to_fp32_table():
     t16 = ops.project_texels_bf16(feats, ops.pack_net_bf16(net))
     torch.cuda.synchronize()
     assert t16.shape == t32.shape
+    pair = ops.project_texels_bf16(feats, ops.pack_net_bf16(net), packed16_b=ops.pack_net_bf16(net))
+    assert torch.equal(pair[0], t16) and torch.equal(pair[1], t16)
     err = (t16 - t32).abs()
     assert err.mean().item() < 4e-3 * t32.abs().mean().item() and err.max().item() < 3e-2 * t32.abs().max().item()

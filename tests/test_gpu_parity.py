@@ -70,6 +70,8 @@ def test_field_eval_texel_table_matches_oracle(n_views, hw, seed):
                                               sc['intrinsics'], sc['extrinsics_inv'], return_taps=True)
     packed = ops.pack_net(d['coarse'])
     table = ops.project_texels(d['features'], packed)
+    both = ops.project_texels2(d['features'], packed, ops.pack_net(d['fine']))      # two nets from one pass over the maps
+    assert torch.equal(both[0], table) and torch.equal(both[1], ops.project_texels(d['features'], ops.pack_net(d['fine'])))
     want = sc['features'].astype(np.float64) @ net['W0'][123:].astype(np.float64)              # (B,V,H,W,128)
     slot = [(((n & 31) >> 2) & 1) * 64 + (n >> 5) * 16 + ((n & 3) + 4 * ((n & 31) >> 3)) for n in range(128)]
     got_table = table.cpu().numpy()[..., slot]                                                 # accumulator order -> natural

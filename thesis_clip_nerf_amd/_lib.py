@@ -34,9 +34,10 @@ SIGNATURES = {
     'mvnerf_query_vjp': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p] * 4),
     'mvnerf_texel_table_bytes': (c_size_t, [c_int] * 4),
     'mvnerf_project_texels': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
+    'mvnerf_project_texels2': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 3),
     'mvnerf_field_eval_table': (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_void_p] * 8),
     'mvnerf_packed_net_bf16_bytes': (c_size_t, []),
-    'mvnerf_project_texels_bf16': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
+    'mvnerf_project_texels_bf16': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 3),
     'mvnerf_pack_net_bf16': (c_int, [c_void_p, c_void_p, c_void_p]),
     'mvnerf_field_eval_bf16': (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_void_p] * 6),
     'mvnerf_field_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

@@ -125,16 +125,25 @@ size_t mvnerf_texel_table_bytes(int B, int V, int H, int W) {
     return (size_t)B * V * H * W * 128 * sizeof(float);
 }
 
-int mvnerf_project_texels(const float* features, const float* packed_net, int B, int V, int H, int W, float* texel_table,
-                          mvnerf_stream_t stream) {
+int mvnerf_project_texels2(const float* features, const float* packed_net, const float* packed_net_b, int B, int V, int H, int W,
+                           float* texel_table, float* texel_table_b, mvnerf_stream_t stream) {
     if (!features || !packed_net || !texel_table) return fail(MVNERF_E_ARG, "mvnerf_project_texels: null pointer");
+    if ((packed_net_b == nullptr) != (texel_table_b == nullptr))
+        return fail(MVNERF_E_ARG, "mvnerf_project_texels2: the second net and the second table go together");
+    if ((packed_net_b && !aligned16(packed_net_b)) || (texel_table_b && !aligned16(texel_table_b)))
+        return fail(MVNERF_E_ALIGN, "mvnerf_project_texels2: packed_net_b, texel_table_b must be 16-byte aligned");
     if (B <= 0 || V <= 0 || H < 2 || W < 2) return fail(MVNERF_E_ARG, "mvnerf_project_texels: B=%d V=%d H=%d W=%d", B, V, H, W);
     if ((long)B * V * H * W >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_project_texels: B*V*H*W too large for int32 indices");
     if (!aligned16(features) || !aligned16(packed_net) || !aligned16(texel_table))
         return fail(MVNERF_E_ALIGN, "mvnerf_project_texels: features, packed_net, texel_table must be 16-byte aligned");
-    return hip_status(mvnerf::launch_project_texels(features, packed_net, (long)B * V * H * W, texel_table,
-                                                    static_cast<hipStream_t>(stream)),
+    return hip_status(mvnerf::launch_project_texels(features, packed_net, packed_net_b, (long)B * V * H * W, texel_table,
+                                                    texel_table_b, static_cast<hipStream_t>(stream)),
                       "mvnerf_project_texels");
+}
+
+int mvnerf_project_texels(const float* features, const float* packed_net, int B, int V, int H, int W, float* texel_table,
+                          mvnerf_stream_t stream) {
+    return mvnerf_project_texels2(features, packed_net, nullptr, B, V, H, W, texel_table, nullptr, stream);
 }
 
 int mvnerf_field_eval_table(const float* rays_o, const float* rays_d, const float* z, const float* images,
@@ -155,14 +164,18 @@ int mvnerf_pack_net_bf16(const float* net_keras, void* packed16, mvnerf_stream_t
     return hip_status(mvnerf::launch_pack_net_bf16(net_keras, packed16, static_cast<hipStream_t>(stream)), "mvnerf_pack_net_bf16");
 }
 
-int mvnerf_project_texels_bf16(const float* features, const void* packed16, int B, int V, int H, int W, float* texel_table,
-                               mvnerf_stream_t stream) {
+int mvnerf_project_texels_bf16(const float* features, const void* packed16, const void* packed16_b, int B, int V, int H, int W,
+                               float* texel_table, float* texel_table_b, mvnerf_stream_t stream) {
     if (!features || !packed16 || !texel_table) return fail(MVNERF_E_ARG, "mvnerf_project_texels_bf16: null pointer");
+    if ((packed16_b == nullptr) != (texel_table_b == nullptr))
+        return fail(MVNERF_E_ARG, "mvnerf_project_texels_bf16: the second net and the second table go together");
+    if ((packed16_b && !aligned16(packed16_b)) || (texel_table_b && !aligned16(texel_table_b)))
+        return fail(MVNERF_E_ALIGN, "mvnerf_project_texels_bf16: packed16_b, texel_table_b must be 16-byte aligned");
     if (B <= 0 || V <= 0 || H < 2 || W < 2) return fail(MVNERF_E_ARG, "mvnerf_project_texels_bf16: B=%d V=%d H=%d W=%d", B, V, H, W);
     if ((long)B * V * H * W >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_project_texels_bf16: B*V*H*W too large for int32 indices");
     if (!aligned16(features) || !aligned16(packed16) || !aligned16(texel_table))
         return fail(MVNERF_E_ALIGN, "mvnerf_project_texels_bf16: features, packed16, texel_table must be 16-byte aligned");
-    return hip_status(mvnerf::launch_project_texels_bf16(features, packed16, (long)B * V * H * W, texel_table,
+    return hip_status(mvnerf::launch_project_texels_bf16(features, packed16, packed16_b, (long)B * V * H * W, texel_table, texel_table_b,
                                                          static_cast<hipStream_t>(stream)),
                       "mvnerf_project_texels_bf16");
 }
@@ -570,8 +583,7 @@ int mvnerf_render_fwd(const float* rays_o, const float* rays_d, const float* ima
     if (texel_tables) {                                       // [coarse net | fine net], mvnerf_texel_table_bytes each
         float* tf = texel_tables + mvnerf_texel_table_bytes(B, V, H, W) / sizeof(float);
         if (!tables_ready) {
-            if ((rc = mvnerf_project_texels(features, packed_coarse, B, V, H, W, texel_tables, stream))) return rc;
-            if ((rc = mvnerf_project_texels(features, packed_fine, B, V, H, W, tf, stream))) return rc;
+            if ((rc = mvnerf_project_texels2(features, packed_coarse, packed_fine, B, V, H, W, texel_tables, tf, stream))) return rc;
         }
         table_c = texel_tables;
         table_f = tf;

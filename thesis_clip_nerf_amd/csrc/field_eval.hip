@@ -382,17 +382,23 @@ __global__ __launch_bounds__(256) void dir_bias_kernel(FieldParams p) {
 // with coalesced 16-byte loads (XOR-swizzled: the B operand read "lane = texel" is then conflict-free); every wave
 // runs 32 steps of 4 k-steps: A = feature groups 8..39 of the packed layer-0 kernel (chunk (g, nb)), B = channels
 // 8q + 4h + {0..3} of this lane's texel.  Two accumulators alternate so consecutive MFMAs do not depend on each other.
-__global__ __launch_bounds__(256) void project_texels_kernel(const float* __restrict__ features,
-                                                             const float* __restrict__ net, long n_texels,
-                                                             float* __restrict__ table) {
+// A second net (net1 / table1, workgroups of 8 waves) shares the staged rows: coarse and fine tables from ONE read of
+// the feature maps.
+__global__ __launch_bounds__(512) void project_texels_kernel(const float* __restrict__ features,
+                                                             const float* __restrict__ net0, const float* __restrict__ net1,
+                                                             long n_texels, float* __restrict__ table0,
+                                                             float* __restrict__ table1) {
     __shared__ __attribute__((aligned(16))) f32x4 srow[32 * 64];
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
-    const int nb = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = wv & 3;
+    const float* net = wv < 4 ? net0 : net1;
+    float* table = wv < 4 ? table0 : table1;
     const long t0 = (long)blockIdx.x * 32;
     const f32x4* fsrc = reinterpret_cast<const f32x4*>(features);
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const int idx = tid + 256 * m;                      // float4 index inside the 32 x 64 block
+    const int nthreads = blockDim.x;
+    for (int m = 0; m < 2048 / nthreads; ++m) {
+        const int idx = tid + nthreads * m;                 // float4 index inside the 32 x 64 block
         const int row = idx >> 6, chunk = idx & 63;
         long t = t0 + row;
         if (t >= n_texels) t = n_texels - 1;
@@ -428,10 +434,10 @@ __global__ __launch_bounds__(256) void project_texels_kernel(const float* __rest
     }
 }
 
-hipError_t launch_project_texels(const float* features, const float* packed_net, long n_texels, float* table,
-                                 hipStream_t stream) {
-    hipLaunchKernelGGL(project_texels_kernel, dim3((unsigned)((n_texels + 31) / 32)), dim3(256), 0, stream, features,
-                       packed_net, n_texels, table);
+hipError_t launch_project_texels(const float* features, const float* packed_net, const float* packed_net1, long n_texels,
+                                 float* table, float* table1, hipStream_t stream) {
+    hipLaunchKernelGGL(project_texels_kernel, dim3((unsigned)((n_texels + 31) / 32)), dim3(packed_net1 ? 512 : 256), 0, stream,
+                       features, packed_net, packed_net1, n_texels, table, table1);
     return hipGetLastError();
 }
 

@@ -170,17 +170,21 @@ __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
 // kernel applies to the gathered features, 16x less matrix time than the fp32 projection (which dominates the bf16
 // path on many-texel scenes).  One workgroup per 32 texels: the rows are staged in LDS as bf16 (coalesced fp32 loads,
 // XOR-swizzled 16-byte chunks), wave nb runs the 16 feature k-steps of output block nb on two alternating accumulators.
-__global__ __launch_bounds__(256) void project_texels_bf16_kernel(const float* __restrict__ features, const f32x4* __restrict__ w16,
-                                                                  long n_texels, float* __restrict__ table) {
+__global__ __launch_bounds__(512) void project_texels_bf16_kernel(const float* __restrict__ features, const f32x4* __restrict__ w16a,
+                                                                  const f32x4* __restrict__ w16b, long n_texels,
+                                                                  float* __restrict__ table0, float* __restrict__ table1) {
     __shared__ __attribute__((aligned(16))) unsigned char srow[32 * 512];          // 32 texels x 256 channels x bf16
     using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
-    const int nb = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = wv & 3;
+    const f32x4* w16 = wv < 4 ? w16a : w16b;               // waves 4..7: the second net on the same staged rows
+    float* table = wv < 4 ? table0 : table1;
     const long t0 = (long)blockIdx.x * 32;
     const f32x4* fsrc = reinterpret_cast<const f32x4*>(features);
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const int idx = tid + 256 * m;                      // float4 index inside the 32 x 64 block
+    const int nthreads = blockDim.x;
+    for (int m = 0; m < 2048 / nthreads; ++m) {
+        const int idx = tid + nthreads * m;                 // float4 index inside the 32 x 64 block
         const int row = idx >> 6, c4 = idx & 63;            // channels 4 c4 .. 4 c4 + 3
         long t = t0 + row;
         if (t >= n_texels) t = n_texels - 1;
@@ -216,9 +220,10 @@ __global__ __launch_bounds__(256) void project_texels_bf16_kernel(const float* _
     }
 }
 
-hipError_t launch_project_texels_bf16(const float* features, const void* packed16, long n_texels, float* table, hipStream_t stream) {
-    hipLaunchKernelGGL(project_texels_bf16_kernel, dim3((unsigned)((n_texels + 31) / 32)), dim3(256), 0, stream, features,
-                       static_cast<const f32x4*>(packed16), n_texels, table);
+hipError_t launch_project_texels_bf16(const float* features, const void* packed16, const void* packed16b, long n_texels, float* table,
+                                      float* table1, hipStream_t stream) {
+    hipLaunchKernelGGL(project_texels_bf16_kernel, dim3((unsigned)((n_texels + 31) / 32)), dim3(packed16b ? 512 : 256), 0, stream,
+                       features, static_cast<const f32x4*>(packed16), static_cast<const f32x4*>(packed16b), n_texels, table, table1);
     return hipGetLastError();
 }
 

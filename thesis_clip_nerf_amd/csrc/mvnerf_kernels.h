@@ -42,11 +42,12 @@ struct FieldParams {
 hipError_t launch_pack_net(const float* net_keras, float* packed, hipStream_t stream);
 hipError_t launch_field_eval(const FieldParams& p, hipStream_t stream);
 hipError_t launch_dir_bias(const FieldParams& p, hipStream_t stream);
-hipError_t launch_project_texels(const float* features, const float* packed_net, long n_texels, float* table,
-                                 hipStream_t stream);
+hipError_t launch_project_texels(const float* features, const float* packed_net, const float* packed_net1, long n_texels,
+                                 float* table, float* table1, hipStream_t stream);
 hipError_t launch_field_jvp(const FieldParams& p, hipStream_t stream);
 hipError_t launch_pack_net_bf16(const float* net_keras, void* packed16, hipStream_t st);
-hipError_t launch_project_texels_bf16(const float* features, const void* packed16, long n_texels, float* table, hipStream_t stream);
+hipError_t launch_project_texels_bf16(const float* features, const void* packed16, const void* packed16b, long n_texels, float* table,
+                                      float* table1, hipStream_t stream);
 hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hipStream_t stream);
 
 hipError_t launch_get_rays(const double* m9, const double* origin3, const float* u, const float* v, int n_rays,

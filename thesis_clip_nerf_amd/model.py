@@ -223,8 +223,7 @@ class MVVNeRFRenderer:
         if ops.texel_table_pays(r, self.n_samples, images.shape[2], images.shape[3]):      # forward value only (section 4.1b)
             if tb.get('tables') is None or tuple(tb['tables'].shape[1:]) != tuple(feats.shape[:4]) + (128,):
                 tb['tables'] = torch.empty((2,) + tuple(feats.shape[:4]) + (128,), dtype=torch.float32, device=self.device)
-            tab_c = ops.project_texels(feats, pc, out=tb['tables'][0])
-            tab_f = ops.project_texels(feats, pf, out=tb['tables'][1])
+            tab_c, tab_f = ops.project_texels2(feats, pc, pf, out=tb['tables']).unbind(0)
         z = ops.stratified_depths(self._dev(u_coarse), self.near, self.far)
         rgbs_c, tb['stash_c'] = ops.field_eval_stash(rays_o, rays_d, z, *geo, pc, tb.get('stash_c'), texel_table=tab_c)
         rgb, depth, w = ops.composite(z, rgbs_c)

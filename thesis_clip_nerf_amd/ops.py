@@ -107,6 +107,23 @@ def project_texels(features, packed_net, out=None):
     return out
 
 
+def project_texels2(features, packed_a, packed_b, out=None):
+    """mvnerf_project_texels2: both nets' tables (2,B,V,H,W,128) [a | b] from one read of the feature maps."""
+    _chk(features, 'features', shape=(None, None, None, None, 256))
+    b, v, h, w, _ = features.shape
+    _chk(packed_a, 'packed_a', shape=(packed_net_floats(),))
+    _chk(packed_b, 'packed_b', shape=(packed_net_floats(),))
+    if out is None:
+        out = torch.empty((2, b, v, h, w, 128), dtype=torch.float32, device=features.device)
+    else:
+        _chk(out, 'texel_tables', shape=(2, b, v, h, w, 128))
+    with torch.cuda.device(features.device):
+        rc = _lib.lib().mvnerf_project_texels2(_p(features), _p(packed_a), _p(packed_b), b, v, h, w, _p(out[0]), _p(out[1]),
+                                               _stream(features))
+    _lib.check(rc, 'project_texels2')
+    return out
+
+
 def field_eval(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, return_taps=False,
                return_pix=False, return_embedding=False, complete_output=False, texel_table=None):
     """mvnerf_field_eval: -> rgbs (B,R,S,4) [+ tap_idx (B,V,R,S,4) int32] [+ pix (B,V,R,S,2)] [+ embedding (B,R,S,128)].
@@ -525,17 +542,24 @@ def pack_net_bf16(net_keras):
     return out
 
 
-def project_texels_bf16(features, packed16, out=None):
-    """mvnerf_project_texels_bf16: the texel table of one net on the bf16 MFMA (fp32 table, same layout as project_texels)."""
+def project_texels_bf16(features, packed16, out=None, packed16_b=None):
+    """mvnerf_project_texels_bf16: the texel table of one net on the bf16 MFMA (fp32 table, same layout as project_texels);
+    with packed16_b both nets' tables (2,B,V,H,W,128) from one read of the feature maps."""
     _chk(features, 'features', shape=(None, None, None, None, 256))
     b, v, h, w, _ = features.shape
-    _chk(packed16, 'packed16', dtype=torch.uint8, shape=(int(_lib.lib().mvnerf_packed_net_bf16_bytes()),))
+    nbytes = int(_lib.lib().mvnerf_packed_net_bf16_bytes())
+    _chk(packed16, 'packed16', dtype=torch.uint8, shape=(nbytes,))
+    shape = (b, v, h, w, 128) if packed16_b is None else (2, b, v, h, w, 128)
+    if packed16_b is not None:
+        _chk(packed16_b, 'packed16_b', dtype=torch.uint8, shape=(nbytes,))
     if out is None:
-        out = torch.empty((b, v, h, w, 128), dtype=torch.float32, device=features.device)
+        out = torch.empty(shape, dtype=torch.float32, device=features.device)
     else:
-        _chk(out, 'texel_table', shape=(b, v, h, w, 128))
+        _chk(out, 'texel_table', shape=shape)
+    t0, t1 = (out, None) if packed16_b is None else (out[0], out[1])
     with torch.cuda.device(features.device):
-        rc = _lib.lib().mvnerf_project_texels_bf16(_p(features), _p(packed16), b, v, h, w, _p(out), _stream(features))
+        rc = _lib.lib().mvnerf_project_texels_bf16(_p(features), _p(packed16), _p(packed16_b), b, v, h, w, _p(t0), _p(t1),
+                                                   _stream(features))
     _lib.check(rc, 'project_texels_bf16')
     return out
 
@@ -585,8 +609,7 @@ def render_fwd_bf16(rays_o, rays_d, images, features, intrinsics, extrinsics_inv
         texel_tables = (torch.empty((2,) + tuple(features.shape[:4]) + (128,), dtype=torch.float32, device=features.device)
                         if texel_table_pays(r, s, h, w_) else None)
     if texel_tables is not None:
-        tab_c = project_texels_bf16(features, packed16_coarse, out=texel_tables[0])
-        tab_f = project_texels_bf16(features, packed16_fine, out=texel_tables[1])
+        tab_c, tab_f = project_texels_bf16(features, packed16_coarse, out=texel_tables, packed16_b=packed16_fine).unbind(0)
     z = stratified_depths(u_coarse, near, far)
     rgbs_c = field_eval_bf16(rays_o, rays_d, z, *geo, packed_coarse, packed16_coarse, texel_table=tab_c)
     rgb, depth, w = composite(z, rgbs_c)
