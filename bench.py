@@ -257,7 +257,13 @@ def cpu_baseline(sc, gpu_out, n_rays):
         ref = run()
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    base = {'value': n_rays / med, 'unit': 'rays/s', 'cores': int(blas_threads), 'kind': 'port',
+    cpu_model = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as f:
+            cpu_model = next((l.split(':', 1)[1].strip() for l in f if l.startswith('model name')), 'unknown')
+    except OSError:
+        pass
+    base = {'value': n_rays / med, 'unit': 'rays/s', 'cores': int(blas_threads), 'kind': 'port', 'cpu_model': cpu_model,
             'sample': f'first {n_rays} of the 4096 rays of the same scene, full 64+128 samples, NumPy fp32 oracle '
                       f'(op-for-op port of the TF graph; BLAS sgemm uses {blas_threads} threads, the rest is single-threaded), '
                       f'median of 3 after 1 warm-up, {med:.2f} s per run; host has {os.cpu_count()} logical cores'}
