@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(lib, name), name
     assert lib.mvnerf_abi_version() == 1
-    assert lib.mvnerf_packed_net_floats() == 251144
+    assert lib.mvnerf_packed_net_floats() == 251656
     assert lib.mvnerf_render_workspace_bytes(1, 1, 4096, 64) == (16 * 64 + 128) * 4096 * 4
     assert lib.mvnerf_field_workspace_bytes(2, 3, 10) == 2 * 3 * 10 * 128 * 4
 

@@ -54,6 +54,9 @@ namespace mvnerf {
 #ifndef MV_FMA_LERP
 #define MV_FMA_LERP 1      // feature lerps as FMAs (6 instead of 9 VALU per channel); taps/indices unaffected
 #endif
+#ifndef MV_VALU_READOUT
+#define MV_VALU_READOUT 1  // 128 -> 4 read-out as 256 FMAs per lane instead of 64 zero-padded MFMAs per tile
+#endif
 #ifndef MV_MV_OCC
 #define MV_MV_OCC 2        // waves per SIMD the multi-view kernels are compiled for: 2 spills the view sum to
                            // scratch (132 B/lane) and is still 5 % faster than 1 (A/B, V=3: 745k -> 786k rays/s)
@@ -310,6 +313,27 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? MV_M
     if (p.embedding && valid) store_acc(p.embedding + 128 * g, h, x);   // optional: trunk output (layers.py:379)
 
     // ---- read-out: Dense 128 -> 4 on relu(x), sigmoid / softplus (layers.py:392-397) ----
+#if MV_VALU_READOUT
+    // on the vector ALU: 64 features per lane x 4 outputs = 256 FMAs, then one cross-half add - the MFMA form pads the
+    // 4 outputs to a 32-row tile (64 MFMAs = 4096 matrix-pipe cycles per tile for 512 useful MACs per sample)
+    f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+    {
+        const f32x4* wr = reinterpret_cast<const f32x4*>(net + kPackWrPlain) + 4 * h;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 w4 = wr[32 * nb + 8 * q + c];
+                    const float a = fmaxf(x[nb][4 * q + c], 0.0f);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = fmaf(a, w4[k], o[k]);
+                }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (o[k] + __shfl_xor(o[k], 32)) + net[kPackBr + k];
+    }
+#else
     // the stream now holds read-out chunks (kb, t = 0..3); rows 0..3 of the 32-row tile are real
     f32x16 o;
 #pragma unroll
@@ -334,6 +358,7 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? MV_M
             for (int t = 0; t < 4; ++t) ws.cur[t] = n[t];
         }
     }
+#endif
     if (valid && h == 0) {
         f32x4 out;
         out[0] = sigmoid_f32(o[0]);
@@ -486,6 +511,8 @@ __global__ void pack_net_kernel(const float* __restrict__ src, float* __restrict
         val = src[kKerasBr + (idx - kPackBr)];
     } else if (idx >= kPackW0Dir && idx < kPackB0Plain) {             // plain W0 rows 60..119 (PE of cam dir)
         val = src[kKerasW0 + 60 * kHidden + (idx - kPackW0Dir)];
+    } else if (idx >= kPackWrPlain) {
+        val = src[kKerasWr + (idx - kPackWrPlain)];
     } else if (idx >= kPackB0Plain) {
         val = src[kKerasB0 + (idx - kPackB0Plain)];
     }

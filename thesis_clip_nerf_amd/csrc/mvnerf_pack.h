@@ -24,7 +24,8 @@ constexpr int kChunkFloats = 256;                       // 64 lanes x 4 floats =
 //               copy below and used as the layer-0 accumulator seed.
 //   12 hidden : 16 groups x 4 nb each, group = (kb, t)
 //   read-out  : 16 chunks (kb, t), output rows i >= 4 zero; consumed 4 chunks per step
-// followed by the biases in accumulator order [h][nb][r], then plain copies of W0 rows 60..119 and b0.
+// followed by the biases in accumulator order [h][nb][r], then plain copies of W0 rows 60..119, b0 and the read-out
+// kernel (the fp32 field kernel evaluates the 128 -> 4 read-out on the vector ALU from that copy).
 constexpr int kL0Groups = 40;
 constexpr int kL0GroupFeat = 8;
 constexpr int kGroupFloats = 4 * kChunkFloats;                         // 1024
@@ -40,7 +41,8 @@ constexpr int kPackBHidden = kPackB0 + 128;                            // 12 x 1
 constexpr int kPackBr = kPackBHidden + kNumHidden * 128;               // 4 (+4 pad)
 constexpr int kPackW0Dir = kPackBr + 8;                                // plain [60][128]: W0 rows 60..119
 constexpr int kPackB0Plain = kPackW0Dir + 60 * 128;                    // plain b0[128]
-constexpr int kPackTotal = kPackB0Plain + 128;                         // 251144 (multiple of 4)
+constexpr int kPackWrPlain = kPackB0Plain + 128;                       // plain read-out kernel [128][4] (Keras order)
+constexpr int kPackTotal = kPackWrPlain + 512;                         // 251656 (multiple of 4)
 
 // feature index held by accumulator register r of lane-half h inside a 32-wide block
 __host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
