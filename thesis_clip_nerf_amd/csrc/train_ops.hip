@@ -203,7 +203,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) rs[r] = 0.0f;
         }
-        // ---- dL/da rows of block w: out[32w + i'][j] = sum_n M[n][32w + i'] G[n][j] ----
+        // ---- dL/da rows of block w: out[32w + i'][j] = sum_n M[n][32w + i'] G[n][j]
+        //      and dW rows of block w: dW[32w + i][n] += sum_j relu(a)[32w + i][j] G[n][j], interleaved group by group:
+        //      the two MFMA chains are independent, so each covers the operand latency of the other ----
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -212,48 +214,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float gcur[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) gcur[e] = sGf[gbase[e]];
+        f32x4 a4[4];
+        f32x4 dgcur = sG[tbase[0]];
+        if (kDW) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a4[t] = sA[tbase[t] + 256 * w];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a4[t][e] = fmaxf(a4[t][e], 0.0f);
+            }
+        }
+        float sgsum = 0.0f;
 #pragma unroll
         for (int grp = 0; grp < 16; ++grp) {
-            // operands of the next group (weights from L2, G from LDS) are requested before this group's MFMAs
+            // operands of the next group (weights from L2, G from LDS in both layouts) are requested before this group's MFMAs
             const f32x4 wnext = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, 4096 * (grp + 1), 0));
             float gnext[4];
             const int gn = grp < 15 ? grp + 1 : grp;
 #pragma unroll
             for (int e = 0; e < 4; ++e)                                          // contraction index n = 32kb + 8t + 4h + e
                 gnext[e] = sGf[gbase[e] + (32 * (gn >> 2) + 8 * (gn & 3)) * 32];
+            f32x4 dgnext = dgcur;
+            if (kDW) dgnext = sG[tbase[gn & 3] + 256 * (gn >> 2)];               // dW group = (output block nb = grp / 4, t = grp % 4)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = mfma(wcur[e], gcur[e], acc);
+            for (int e = 0; e < 4; ++e) {
+                acc = mfma(wcur[e], gcur[e], acc);
+                if (kDW) {
+                    dwacc[grp >> 2] = mfma(a4[grp & 3][e], dgcur[e], dwacc[grp >> 2]);
+                    sgsum = sgsum + dgcur[e];
+                }
+            }
+            if (kDW && (grp & 3) == 3) {
+                dbacc[grp >> 2] = dbacc[grp >> 2] + sgsum;
+                sgsum = 0.0f;
+            }
             wcur = wnext;
+            dgcur = dgnext;
 #pragma unroll
             for (int e = 0; e < 4; ++e) gcur[e] = gnext[e];
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- dW rows of block w: dW[32w + i][n] += sum_j relu(a)[32w + i][j] G[n][j] ----
-        if (kDW) {
-        f32x4 a4[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a4[t] = sA[tbase[t] + 256 * w];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a4[t][e] = fmaxf(a4[t][e], 0.0f);
-        }
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            float sgsum = 0.0f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f32x4 g4 = sG[tbase[t] + 256 * nb];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    dwacc[nb] = mfma(a4[t][e], g4[e], dwacc[nb]);
-                    sgsum = sgsum + g4[e];
-                }
-            }
-            dbacc[nb] = dbacc[nb] + sgsum;
-            __builtin_amdgcn_sched_barrier(0);             // keep one block's 16 LDS operands live at a time
-        }
-        }
         // ---- epilogue of dL/da: relu mask from the staged a tile, optional residual, store ----
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
