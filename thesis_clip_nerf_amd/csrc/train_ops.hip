@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         f32x4 wcur = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, 0, 0));
+        f32x4 wnxt = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, 4096, 0));
         const float* sGf = reinterpret_cast<const float*>(sG);
         float gcur[4];
 #pragma unroll
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int grp = 0; grp < 16; ++grp) {
             // operands of the next group (weights from L2, G from LDS in both layouts) are requested before this group's MFMAs
-            const f32x4 wnext = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, 4096 * (grp + 1), 0));
+            // (the weights, an L2 round trip, two groups ahead; past the end of the stream the buffer range check returns 0)
+            const f32x4 wnext2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, 4096 * (grp + 2), 0));
             float gnext[4];
             const int gn = grp < 15 ? grp + 1 : grp;
 #pragma unroll
@@ -249,7 +251,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 dbacc[grp >> 2] = dbacc[grp >> 2] + sgsum;
                 sgsum = 0.0f;
             }
-            wcur = wnext;
+            wcur = wnxt;
+            wnxt = wnext2;
             dgcur = dgnext;
 #pragma unroll
             for (int e = 0; e < 4; ++e) gcur[e] = gnext[e];
