@@ -54,9 +54,6 @@ namespace mvnerf {
 #ifndef MV_FMA_LERP
 #define MV_FMA_LERP 1      // feature lerps as FMAs (6 instead of 9 VALU per channel); taps/indices unaffected
 #endif
-#ifndef MV_VALU_READOUT
-#define MV_VALU_READOUT 1  // 128 -> 4 read-out as 256 FMAs per lane instead of 64 zero-padded MFMAs per tile
-#endif
 #ifndef MV_MV_OCC
 #define MV_MV_OCC 2        // waves per SIMD the multi-view kernels are compiled for: 2 spills the view sum to
                            // scratch (132 B/lane) and is still 5 % faster than 1 (A/B, V=3: 745k -> 786k rays/s)
@@ -207,7 +204,7 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? MV_M
 #pragma unroll
         for (int gq = 0; gq < 8; ++gq) {
             const float bb[4] = {pe[4 * gq], pe[4 * gq + 1], pe[4 * gq + 2], pe[4 * gq + 3]};
-            if (kProj && gq == 7) ws.pos = kPackHidden * 4;           // the stream skips the 32 feature groups
+            if (kProj && gq == 7 - ws_jump_lead()) ws.pos = kPackHidden * 4;   // the stream skips the 32 feature groups
             mfma_step(ws, bb, x);
         }
         if (kProj) {
@@ -313,7 +310,6 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? MV_M
     if (p.embedding && valid) store_acc(p.embedding + 128 * g, h, x);   // optional: trunk output (layers.py:379)
 
     // ---- read-out: Dense 128 -> 4 on relu(x), sigmoid / softplus (layers.py:392-397) ----
-#if MV_VALU_READOUT
     // on the vector ALU: 64 features per lane x 4 outputs = 256 FMAs, then one cross-half add - the MFMA form pads the
     // 4 outputs to a 32-row tile (64 MFMAs = 4096 matrix-pipe cycles per tile for 512 useful MACs per sample)
     f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -333,32 +329,6 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? MV_M
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = (o[k] + __shfl_xor(o[k], 32)) + net[kPackBr + k];
     }
-#else
-    // the stream now holds read-out chunks (kb, t = 0..3); rows 0..3 of the 32-row tile are real
-    f32x16 o;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = (r < 4) ? net[kPackBr + r] : 0.0f;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        f32x4 n[4];
-        if (kb < 3) {
-            n[0] = ws_load<0>(ws, ws.pos);
-            n[1] = ws_load<1024>(ws, ws.pos);
-            n[2] = ws_load<2048>(ws, ws.pos);
-            n[3] = ws_load<3072>(ws, ws.pos);
-            ws.pos += 4096;
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o = mfma(ws.cur[t][e], fmaxf(x[kb][4 * t + e], 0.0f), o);
-        }
-        if (kb < 3) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) ws.cur[t] = n[t];
-        }
-    }
-#endif
     if (valid && h == 0) {
         f32x4 out;
         out[0] = sigmoid_f32(o[0]);

@@ -51,15 +51,22 @@ __device__ __forceinline__ void relu4(const float (&in)[4], float (&b)[4]) {
 #endif
 }
 
-// The weight stream: `cur` holds the 4 chunks (4 KiB per wave) of the step being consumed, `next`
-// points at this lane's 16 bytes of the following step.  Every step first issues the loads of the
-// following step, then runs its 16 MFMAs (1024 cycles of matrix pipe), so an L2 round trip is
-// always covered, also across layer boundaries (the chunks of all layers are contiguous).
+// The weight stream: `cur` holds the 4 chunks (4 KiB per wave) of the step being consumed.  Every step first
+// requests a later step (MV_WS_AHEAD steps on), then runs its 16 MFMAs (1024 cycles of matrix pipe), so an L2
+// round trip is covered with margin, also across layer boundaries (the chunks of all layers are contiguous).
+#ifndef MV_WS_AHEAD
+#define MV_WS_AHEAD 1      // steps (of 4 KiB per wave) the weight stream is requested ahead of use: 1 or 2 (2: measured
+                           // -0.6 %: the 16 extra registers push the 255-register kernels into scratch)
+#endif
+
 struct WStream {
     __amdgpu_buffer_rsrc_t rsrc;   // buffer descriptor of the packed net (SGPRs)
     int voff;                      // lane * 16
-    int pos;                       // wave-uniform byte offset of the NEXT step (SGPR)
+    int pos;                       // wave-uniform byte offset of the step to REQUEST next (SGPR)
     f32x4 cur[4];
+#if MV_WS_AHEAD == 2
+    f32x4 nxt[4];                  // the step after `cur`, already in flight / landed
+#endif
 };
 
 // buffer_load_dwordx4 v, voff, rsrc, pos offen offset:imm -- the uniform stream position rides in the
@@ -72,14 +79,44 @@ __device__ __forceinline__ f32x4 ws_load(const WStream& ws, int pos) {
 }
 
 __device__ __forceinline__ void ws_begin(WStream& ws, const float* base, int bytes, int lane) {
-    // loads past `bytes` (the prefetch of the step after the last one) return 0 by the buffer range check
+    // loads past `bytes` (the prefetch of the steps after the last one) return 0 by the buffer range check
     ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
     ws.voff = lane * 16;
     ws.cur[0] = ws_load<0>(ws, 0);
     ws.cur[1] = ws_load<1024>(ws, 0);
     ws.cur[2] = ws_load<2048>(ws, 0);
     ws.cur[3] = ws_load<3072>(ws, 0);
+#if MV_WS_AHEAD == 2
+    ws.nxt[0] = ws_load<0>(ws, 4096);
+    ws.nxt[1] = ws_load<1024>(ws, 4096);
+    ws.nxt[2] = ws_load<2048>(ws, 4096);
+    ws.nxt[3] = ws_load<3072>(ws, 4096);
+    ws.pos = 8192;
+#else
     ws.pos = 4096;
+#endif
+}
+
+// The stream jumps: the step consumed kAfter steps from now (0 = the next mfma_step) shall come from byte offset `to`.
+// With a request distance of MV_WS_AHEAD the redirect has to be announced MV_WS_AHEAD - 1 steps earlier than with 1.
+__device__ __forceinline__ constexpr int ws_jump_lead() { return MV_WS_AHEAD - 1; }
+
+// rotate the stream after a step whose next-request is n0..n3
+__device__ __forceinline__ void ws_advance(WStream& ws, f32x4 n0, f32x4 n1, f32x4 n2, f32x4 n3) {
+#if MV_WS_AHEAD == 2
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ws.cur[q] = ws.nxt[q];
+    ws.nxt[0] = n0;
+    ws.nxt[1] = n1;
+    ws.nxt[2] = n2;
+    ws.nxt[3] = n3;
+#else
+    ws.cur[0] = n0;
+    ws.cur[1] = n1;
+    ws.cur[2] = n2;
+    ws.cur[3] = n3;
+#endif
+    ws.pos += 4096;
 }
 
 // One step = 4 k-steps x 4 output blocks: acc[nb] += A(cur[nb])[e] x b[e]
@@ -91,7 +128,7 @@ __device__ __forceinline__ void mfma_step(WStream& ws, const float (&b)[4], f32x
                 n3 = ws_load<3072>(ws, ws.pos);
 #endif
 #if MV_PIN_LOADS
-    __builtin_amdgcn_sched_barrier(0);      // keep the prefetch a full step ahead of its use
+    __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of its use
 #endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -100,11 +137,7 @@ __device__ __forceinline__ void mfma_step(WStream& ws, const float (&b)[4], f32x
         acc[2] = mfma(ws.cur[2][e], b[e], acc[2]);
         acc[3] = mfma(ws.cur[3][e], b[e], acc[3]);
     }
-    ws.cur[0] = n0;
-    ws.cur[1] = n1;
-    ws.cur[2] = n2;
-    ws.cur[3] = n3;
-    ws.pos += 4096;
+    ws_advance(ws, n0, n1, n2, n3);
 }
 
 

@@ -36,11 +36,7 @@ __device__ __forceinline__ void mfma_step2(WStream& ws, const float (&b)[4], con
             tacc[nb] = mfma(ws.cur[nb][e], tb[e], tacc[nb]);
         }
     }
-    ws.cur[0] = n0;
-    ws.cur[1] = n1;
-    ws.cur[2] = n2;
-    ws.cur[3] = n3;
-    ws.pos += 4096;
+    ws_advance(ws, n0, n1, n2, n3);
 }
 
 // acc += W^T relu(in) ; tacc += W^T (relu'(in) (.) tin)
