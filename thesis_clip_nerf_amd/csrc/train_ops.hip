@@ -796,12 +796,19 @@ struct SampleGeom {       // per sample, in wave-private LDS
     int tl;
 };
 
+// The 120 positional-encoding rows are evaluated per tile in "lane = sample" form - 6 accurate sin/cos and the
+// forward kernel's double-angle recurrence per sample instead of one libm-grade sin/cos per (row, sample) - into a
+// wave-private LDS table [sample][121] and read back transposed as A operands (blockIdx.y == 0 only).
+constexpr int kPeRow = 121;           // odd row stride: conflict-free "lane = sample" writes
+
 __global__ __launch_bounds__(256) void dw0_kernel(FieldParams p, const float* __restrict__ g0_tl, float* __restrict__ dW0,
-                                                  float* __restrict__ db0) {
+                                                  float* __restrict__ db0, int y0) {
     __shared__ SampleGeom geom[4][32];
+    extern __shared__ float pe_lds[];                      // 4 x 32 x kPeRow floats for the launch with the PE row blocks
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int kb = blockIdx.y * 4 + w;                     // 12 row blocks of 32 (384 >= 379)
+    float* pe_tab = pe_lds + w * (32 * kPeRow);
+    const int kb = (blockIdx.y + y0) * 4 + w;              // 12 row blocks of 32 (384 >= 379)
     const int krow = 32 * kb + i;
     f32x16 acc[4];
     float dbacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -838,6 +845,29 @@ __global__ __launch_bounds__(256) void dw0_kernel(FieldParams p, const float* __
             gm[i] = sg;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (kb < 4) {                                      // wave-uniform: this wave's rows include PE rows
+            // lane (sample i, half h): h = 0 the camera point, h = 1 the camera direction; rows 60h + 20d + 2k + {sin, cos}
+            const SampleGeom sgm = gm[i];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float a0 = (h ? sgm.dir[d] : sgm.cam[d]) * 3.14159274101257324f;
+                float sk = 0.0f, ck = 0.0f;
+#pragma unroll
+                for (int k = 0; k < kNFreq; ++k) {
+                    if (k == 0 || k == 5) {
+                        sincos_f32(a0 * (float)(1 << k), &sk, &ck);
+                    } else {                               // octave k is the double angle of octave k - 1 (field_eval.hip)
+                        const float s2 = sk + sk;
+                        const float cn = fmaf(-s2, sk, 1.0f);
+                        sk = s2 * ck;
+                        ck = cn;
+                    }
+                    pe_tab[i * kPeRow + 60 * h + 20 * d + 2 * k] = sk;
+                    pe_tab[i * kPeRow + 60 * h + 20 * d + 2 * k + 1] = ck;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         f32x4 a4[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -846,11 +876,7 @@ __global__ __launch_bounds__(256) void dw0_kernel(FieldParams p, const float* __
                 const SampleGeom sg = gm[8 * t + 4 * h + e];
                 float v = 0.0f;
                 if (krow < 120) {                          // positional encodings, layout (d, k, {sin,cos})
-                    const int m = krow < 60 ? krow : krow - 60;
-                    const float x = krow < 60 ? sg.cam[m / 20] : sg.dir[m / 20];
-                    float sv, cv;
-                    sincos_f32(x * (3.14159274101257324f * (float)(1 << ((m % 20) >> 1))), &sv, &cv);
-                    v = (m & 1) ? cv : sv;
+                    v = pe_tab[(8 * t + 4 * h + e) * kPeRow + krow];
                 } else if (krow < 123) {
                     const float* im = p.images + 3 * (long)sg.tl + (krow - 120);
                     v = bilerp(im[0] * 2.0f - 1.0f, im[3] * 2.0f - 1.0f, im[3 * p.W] * 2.0f - 1.0f,
@@ -895,7 +921,20 @@ __global__ __launch_bounds__(256) void dw0_kernel(FieldParams p, const float* __
 hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, float* db0, int max_wgs, hipStream_t st) {
     const long view_tiles = p.n_tiles * p.V;
     const unsigned wgs = (unsigned)(view_tiles < max_wgs ? view_tiles : max_wgs);
-    hipLaunchKernelGGL(dw0_kernel, dim3(wgs, 3), dim3(256), 0, st, p, g0_tl, dW0, db0);
+    // two launches: row blocks 0..3 (PE rows; 62 KiB of PE tables per workgroup) and row blocks 4..11 (feature rows, no
+    // dynamic LDS, full occupancy)
+    static std::atomic<bool> attr_done[16];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const int pe_bytes = 4 * 32 * kPeRow * (int)sizeof(float);
+    if (dev >= 0 && dev < 16 && !attr_done[dev].load(std::memory_order_acquire)) {
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pe_bytes)) != hipSuccess)
+            return e;
+        attr_done[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(dw0_kernel, dim3(wgs, 1), dim3(256), pe_bytes, st, p, g0_tl, dW0, db0, 0);
+    hipLaunchKernelGGL(dw0_kernel, dim3(wgs, 2), dim3(256), 0, st, p, g0_tl, dW0, db0, 1);
     return hipGetLastError();
 }
 
