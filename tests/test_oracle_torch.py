@@ -55,3 +55,38 @@ def _loss(cf, ff, y, sc, stop):
                             t(sc['extrinsics_inv']), t(sc['features']), sc['near'], sc['far'], 64, t(sc['u_coarse']),
                             t(sc['u_fine']), stop_fine_z=stop)
     return float(((t(y) - out[0]) ** 2).mean() + ((t(y) - out[2]) ** 2).mean())
+
+
+def test_query_acts_matches_numpy_oracle_and_finite_differences():
+    """The torch twin of the trunk-as-a-field (LanguageNeRF's use, oracle/mvnerf_torch.query_acts) against the NumPy oracle's
+    complete_output on the same points, and its input Jacobian against central differences in float64."""
+    sc = make_scene(seed=33, batch=2, n_views=2, height=10, width=12, n_rays=5, bias_scale=0.05)
+    rng = np.random.default_rng(0)
+    pts = (sc['rays_o'] + 0.8 * sc['rays_d']).astype(np.float32)
+    dirs = rng.standard_normal(pts.shape).astype(np.float32)
+    net_np = O.unflatten_net(sc['fine'])
+    # NumPy oracle: one sample per point (z = 0 along a zero-length step: world point = origin)
+    world = pts[:, :, None, :]
+    pix, cam = O.compute_pixel_in_image_mv(world, sc['intrinsics'], sc['extrinsics_inv'])
+    b, v = sc['images'].shape[:2]
+    n = pts.shape[1]
+    feat = O.get_projection_features_mv((sc['images'] * np.float32(2.0) - np.float32(1.0)).astype(np.float32), sc['features'], pix)
+    cdir = O.world_to_camera_direction_vector_mv(dirs, sc['extrinsics_inv'])
+    cdir = np.broadcast_to(cdir[:, :, :, None, :], (b, v, n, 1, 3))
+    outs = O.mv_embedding(net_np, cam[..., :3].reshape(b * v, n, 1, 3), cdir.reshape(b * v, n, 1, 3), feat.reshape(b * v, n, 1, -1), v,
+                          complete_output=True)
+    t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    net_t = T.unflatten_net(t32(sc['fine']))
+    acts = T.query_acts(net_t, t32(pts), t32(dirs), t32(sc['images']), t32(sc['features']), t32(sc['intrinsics']), t32(sc['extrinsics_inv']))
+    for k in range(4):
+        assert np.abs(acts[k].numpy() - outs[4 + k][:, :, 0]).max() < 2e-5
+    # Jacobian-vector product by autograd vs central differences (float64, small step: the PE has gain pi * 2^9)
+    t64 = lambda a: torch.as_tensor(np.asarray(a)).double()
+    net64 = T.unflatten_net(t64(sc['fine']))
+    geo = (t64(sc['images']), t64(sc['features']), t64(sc['intrinsics']), t64(sc['extrinsics_inv']))
+    f = lambda p_, d_: torch.stack(T.query_acts(net64, p_, d_, *geo), 0)
+    tp, td = t64(rng.standard_normal(pts.shape)), t64(rng.standard_normal(pts.shape))
+    _, jv = torch.autograd.functional.jvp(f, (t64(pts), t64(dirs)), (tp, td))
+    eps = 1e-7
+    fd = (f(t64(pts) + eps * tp, t64(dirs) + eps * td) - f(t64(pts) - eps * tp, t64(dirs) - eps * td)) / (2 * eps)
+    assert float((jv - fd).norm() / fd.norm()) < 1e-5
