@@ -309,10 +309,6 @@ int mvnerf_finish_view(const float* rgb, const float* depth, long n, float* minm
 // ---- training --------------------------------------------------------------------------------------------
 namespace {
 long tiles_for(int B, int R, int S) { return ((long)B * R * S + 31) / 32; }
-#ifndef MV_BLOCK_BWD
-#define MV_BLOCK_BWD 0      // 1: one kernel per ResNet block in the backward (4 instead of 7 tile transfers per block,
-                            // but 3 barriers per tile and 128 B/lane of scratch: measured 13.85 vs 13.43 ms per step)
-#endif
 constexpr int kBwdMaxWGs = 512;      // resident workgroups of the dW kernels (2 per CU)
 constexpr int kFusedBwdWGs = 512;    // fused dX+dW kernel: 2 waves/SIMD by registers -> 2 resident workgroups per CU
 }  // namespace
@@ -428,21 +424,12 @@ int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float*
         const float* pre_hid = fused ? fused_slot(2 * (bi - 3) + 1) : view_slot(2 * bi + 1);
         float* gb = grad + kKerasBlocks + bi * kKerasBlockStride;
         const int dh = (g + 1) % 3, gn = (g + 2) % 3;
-#if MV_BLOCK_BWD
-        // both Dense layers of the block in one pass over the tiles (dHid stays in LDS)
-        (void)dh;
-        MV_TRY(launch_block_bwd_fused(buf[g], pre_hid, pre_in, bwd_streams + (size_t)(2 * bi + 1) * kHiddenWFloats,
-                                      bwd_streams + (size_t)(2 * bi) * kHiddenWFloats, buf[gn], nt,
-                                      gb + kHidden * kHidden + kHidden, gb + 2 * kHidden * kHidden + kHidden, gb,
-                                      gb + kHidden * kHidden, kFusedBwdWGs, st));
-#else
         // second Dense of the block: out = x_in + W2^T relu(hid) + b2      (dX and dW in one pass over the tiles)
         MV_TRY(launch_dense_bwd_fused(buf[g], pre_hid, bwd_streams + (size_t)(2 * bi + 1) * kHiddenWFloats, nullptr, buf[dh], nt,
                                       gb + kHidden * kHidden + kHidden, gb + 2 * kHidden * kHidden + kHidden, kFusedBwdWGs, st));
         // first Dense: hid = W1^T relu(x_in) + b1 ; the identity branch adds dL/d(out) back
         MV_TRY(launch_dense_bwd_fused(buf[dh], pre_in, bwd_streams + (size_t)(2 * bi) * kHiddenWFloats, buf[g], buf[gn], nt, gb,
                                       gb + kHidden * kHidden, kFusedBwdWGs, st));
-#endif
         g = gn;
     }
     // layer 0 (inputs recomputed)

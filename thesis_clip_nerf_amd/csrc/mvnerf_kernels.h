@@ -85,9 +85,6 @@ hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int 
                           int n_valid, float* db, int max_wgs, hipStream_t st);
 hipError_t launch_dense_bwd_fused(const float* g_tl, const float* a_tl, const float* wstream, const float* resid_tl,
                                   float* da_tl, long n_tiles, float* dW, float* db, int max_wgs, hipStream_t st);
-hipError_t launch_block_bwd_fused(const float* g_tl, const float* hid_tl, const float* x_tl, const float* w2t, const float* w1t,
-                                  float* dx_tl, long n_tiles, float* dW2, float* db2, float* dW1, float* db1, int max_wgs,
-                                  hipStream_t st);
 hipError_t launch_mse_grad(const float* pred, const float* label, long n, float* d_pred, float* loss, hipStream_t st);
 hipError_t launch_composite_bwd(const float* z, const float* rgbs, const float* d_rgb, const float* d_depth,
                                 const float* d_w, int n_rays, int S, float* d_rgbs, float* d_z, hipStream_t st);
