@@ -5,7 +5,9 @@ The reference module `src/lib/mvnerf/nerf_utils.py` imports TensorFlow at the to
 installed here (ordinary ModuleNotFoundError), so the three pure-NumPy functions
 (`get_rays`, `get_specific_rays`, `bbox_biased_sample`, nerf_utils.py:15-46) are pulled out of the
 parsed source with `ast` and executed with only {np, rearrange, repeat} in scope.  Likewise
-`camera_parameters` from data_generator/util.py:4-10.  Only inputs and outputs are stored.
+`camera_parameters` from data_generator/util.py:4-10 and the three NumPy methods `generate_rays`,
+`get_input`, `get_target` of data_generator/mvnerf.py:16-48 (the module imports a package whose
+submodule is absent).  Only inputs and outputs are stored.
 
     python tests/golden/make_golden.py
 """
@@ -28,6 +30,18 @@ def extract(path, names):
     scope = {'np': np, 'rearrange': rearrange, 'repeat': repeat}
     exec(compile(ast.Module(body=keep, type_ignores=[]), path, 'exec'), scope)
     return [scope[n] for n in names]
+
+
+def extract_methods(path, cls_name, names, scope_extra):
+    """The named methods of one class of the reference, as a bare class (no base, no __init__)."""
+    tree = ast.parse(open(path).read())
+    (cls,) = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls_name]
+    keep = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(keep) == len(names), [n.name for n in keep]
+    bare = ast.ClassDef(name=cls_name, bases=[], keywords=[], body=keep, decorator_list=[])
+    scope = {'np': np, **scope_extra}
+    exec(compile(ast.fix_missing_locations(ast.Module(body=[bare], type_ignores=[])), path, 'exec'), scope)
+    return scope[cls_name]
 
 
 def main():
@@ -73,6 +87,41 @@ def main():
         s = bbox_biased_sample(512, np.array([100, 200, 300, 500]), 480, 640)
         out[f'seed{seed}_bbox'] = s
     np.savez_compressed(os.path.join(HERE, 'pixel_idx.npz'), **out)
+
+    # a3 caller side (data_generator/mvnerf.py:16-48): generate_rays ((row, col) -> (u, v) -> rays), get_target and
+    # get_input of the reference's MVNeRFDataGenerator, executed as plain methods of a bare class
+    gen_cls = extract_methods(os.path.join(REF, 'data_generator', 'mvnerf.py'), 'MVNeRFDataGenerator',
+                              ['generate_rays', 'get_input', 'get_target'],
+                              {'bbox_biased_sample': bbox_biased_sample, 'get_specific_rays': get_specific_rays,
+                               'camera_parameters': camera_parameters})
+    out = {}
+    rng = np.random.default_rng(4321)
+    for i, (h, w, n, n_src) in enumerate([(16, 20, 48, 2), (64, 64, 512, 1), (30, 40, 100, 3)]):
+        gen = object.__new__(gen_cls)
+        gen.n_rays_train = n
+        color = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        cam = {'pose': ring_pose(rng.uniform(0, 2 * np.pi), radius=rng.uniform(0.6, 1.0)),
+               'intrinsics': pinhole(w, h, focal_scale=rng.uniform(0.7, 1.2)).reshape(-1)}
+        np.random.seed(100 + i)
+        r_d, r_o, rays = gen.generate_rays(color, cam)
+        target = gen_cls.get_target(color, rays)
+        src_colors = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(n_src)]
+        src_cams = [{'pose': ring_pose(rng.uniform(0, 2 * np.pi)), 'intrinsics': cam['intrinsics']} for _ in range(n_src)]
+        inputs = gen_cls.get_input(src_colors, src_cams, r_d, r_o)
+        out[f'case{i}_seed'] = np.array(100 + i)
+        out[f'case{i}_n'] = np.array(n)
+        out[f'case{i}_color'] = color
+        out[f'case{i}_pose'] = cam['pose']
+        out[f'case{i}_intrinsics'] = cam['intrinsics']
+        out[f'case{i}_r_d'] = r_d
+        out[f'case{i}_r_o'] = np.array(r_o)
+        out[f'case{i}_rays'] = rays
+        out[f'case{i}_target'] = target
+        out[f'case{i}_src_colors'] = np.array(src_colors)
+        out[f'case{i}_src_poses'] = np.array([c['pose'] for c in src_cams])
+        for j, a in enumerate(inputs):
+            out[f'case{i}_input{j}'] = a
+    np.savez_compressed(os.path.join(HERE, 'datagen.npz'), **out)
     print('wrote', os.listdir(HERE))
 
 

@@ -280,8 +280,10 @@ class MVVNeRFRenderer:
         if self._grad_sync is not None:
             self._grad_sync(grad)                         # one flat collective for both MLPs
         o = self._opt
-        o['step'] += 1
+        # Keras evaluates the schedule at `optimizer.iterations` BEFORE the increment (0 on the first step: the warm-up's
+        # first update has lr = 0); only the Adam bias correction uses iterations + 1
         lr = o['lr'](o['step']) if callable(o['lr']) else o['lr']
+        o['step'] += 1
         lr_t = lr * np.sqrt(1.0 - o['b2'] ** o['step']) / (1.0 - o['b1'] ** o['step'])
         for k, net in enumerate((self.coarse_net, self.fine_net)):
             sl = slice(k * NET_PARAMS, (k + 1) * NET_PARAMS)

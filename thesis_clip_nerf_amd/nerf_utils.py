@@ -112,15 +112,19 @@ def get_projection_features_mv(inputs, features, pixel_locations, n_rays, n_samp
 
 
 class WarmupScheduler:
-    """nerf_utils.py:288-300: linear warm-up -> constant -> x0.1 after `scale_down_after` steps."""
+    """nerf_utils.py:288-300: linear warm-up -> constant -> x0.1 after `scale_down_after` steps.  float32 arithmetic as the
+    reference (`tf.cast(step, tf.float32)`; `step / warmup * target` evaluated left to right); called with the optimizer's
+    iteration count BEFORE the update (0 on the first step), as Keras does."""
 
     def __init__(self, target_learning_rate, warmup_steps, scale_down_after=400000):
-        self.target_learning_rate = float(target_learning_rate)
-        self.warmup_steps = max(1.0, float(warmup_steps))
-        self.scale_down_after = float(scale_down_after)
+        self.target_learning_rate = np.float32(target_learning_rate)
+        self.warmup_steps = max(np.float32(1.0), np.float32(warmup_steps))
+        self.scale_down_after = np.float32(scale_down_after)
 
     def __call__(self, step):
-        step = float(step)
+        step = np.float32(step)
         if step <= self.warmup_steps:
-            return step / self.warmup_steps * self.target_learning_rate
-        return self.target_learning_rate if step <= self.scale_down_after else 0.1 * self.target_learning_rate
+            return float(np.float32(step / self.warmup_steps) * self.target_learning_rate)
+        if step <= self.scale_down_after:
+            return float(self.target_learning_rate)
+        return float(np.float32(0.1) * self.target_learning_rate)

@@ -74,14 +74,23 @@ def glorot_net(rng, bias_scale=0.0):
     return flat
 
 
+def _draw_features(rng, shape, sigma, as_f32):
+    if as_f32:
+        return np.float32(sigma) * rng.standard_normal(shape, dtype=np.float32)
+    return (sigma * rng.standard_normal(shape)).astype(np.float32)
+
+
 def make_scene(seed=0, batch=1, n_views=1, height=64, width=64, n_rays=None, n_samples=64,
-               bias_scale=0.0, feature_sigma=0.5):
+               bias_scale=0.0, feature_sigma=0.5, features32=False, with_features=True):
     """All inputs of one `_call` (model_v0.py:113) as NumPy fp32 arrays.
 
     n_rays=None -> every pixel of a `height x width` target view (row-major), i.e. H*W rays.
     Returns a dict: rays_o, rays_d (B,R,3); images (B,V,H,W,3); features (B,V,H,W,256);
     intrinsics, extrinsics_inv (B,V,4,4); u_coarse (B,R,S); u_fine (B,R,S); coarse, fine (flat
     nets); near, far; tgt_pose (B,4,4 f64); tgt_intrinsics (3,3 f32).
+    features32: draw the feature maps directly as float32 (480x640 maps: no float64 temporary; a different random
+    stream than the default, so values differ from features32=False).  with_features=False: `features` is None (the
+    caller fills large maps on the device).
     """
     rng = np.random.default_rng(seed)
     k3 = pinhole(width, height)
@@ -113,7 +122,7 @@ def make_scene(seed=0, batch=1, n_views=1, height=64, width=64, n_rays=None, n_s
     scene = dict(
         rays_o=np.stack(rays_o), rays_d=np.stack(rays_d),
         images=rng.random((batch, n_views, height, width, 3), dtype=np.float32),
-        features=(feature_sigma * rng.standard_normal((batch, n_views, height, width, 256))).astype(np.float32),
+        features=_draw_features(rng, (batch, n_views, height, width, 256), feature_sigma, features32) if with_features else None,
         intrinsics=np.asarray(kk, dtype=np.float32), extrinsics_inv=np.asarray(einv, dtype=np.float32),
         u_coarse=rng.random((batch, r, n_samples), dtype=np.float32),
         u_fine=rng.random((batch, r, n_samples), dtype=np.float32),

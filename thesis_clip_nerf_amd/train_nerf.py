@@ -97,6 +97,13 @@ class MVNeRFDataGenerator:
     def get_target(color, rays):
         return np.array(color[rays[:, 0], rays[:, 1], :3]) / 255.0                       # mvnerf.py:45-48
 
+    @staticmethod
+    def get_input(colors, camera_configs, r_d, r_o):
+        """mvnerf.py:27-43: one scene's network inputs (rays_o, rays_d, images in [0,1], K4, E^-1), float32, batch axis 1."""
+        cams = [camera_parameters(c) for c in camera_configs]
+        f32 = lambda a: np.array([a], dtype=np.float32)
+        return (f32(r_o), f32(r_d), f32(np.array(colors) / 255.0), f32([c[1] for c in cams]), f32([c[0] for c in cams]))
+
     def _view(self, i, p):
         """Device-resident (image float (H,W,3) in [0,1], colour uint8, features, E^-1, K4) of scene i, perspective p."""
         key = (int(i), int(p))
@@ -110,24 +117,32 @@ class MVNeRFDataGenerator:
                                    torch.from_numpy(einv.astype(np.float32)).to(dev), torch.from_numpy(k4.astype(np.float32)).to(dev))
         return self._resident[key]
 
-    def get_data_device(self, batch):
-        """get_data with the batch assembled on the GPU; consumes the NumPy RNG exactly like get_data."""
+    def generate_rays_device(self, color, camera_config):
+        """generate_rays (mvnerf.py:16-25) with the rays made on the GPU: pixel indices from the host NumPy RNG (the reference's
+        stream), (row, col) -> (u = col, v = row), mvnerf_get_rays on those.  Returns (r_d, r_o, px (n,2) int64 device)."""
         from . import ops
         dev = self.device
+        rays = bbox_biased_sample(self.n_rays_train, np.array([0, 0, color.shape[0], color.shape[1]]), color.shape[0], color.shape[1])
+        k = np.reshape(camera_config['intrinsics'], (3, 3)).astype(np.float32)
+        m = camera_config['pose'][:3, :3] @ np.linalg.inv(k)                              # as generate_rays (host LAPACK)
+        px = torch.from_numpy(np.ascontiguousarray(rays)).to(dev)                          # (n,2) int64 (row, col)
+        r_o, r_d = ops.get_rays_device(m, camera_config['pose'][:3, -1], dev, u=px[:, 1].to(torch.float32).contiguous(),
+                                       v=px[:, 0].to(torch.float32).contiguous())
+        return r_d, r_o, px
+
+    @staticmethod
+    def get_target_device(color_u8, px):
+        """get_target (mvnerf.py:45-48) as a device gather: color_u8 (H,W,3) uint8, px (n,2) (row, col)."""
+        return color_u8[px[:, 0], px[:, 1], :3].to(torch.float32) / 255.0
+
+    def get_data_device(self, batch):
+        """get_data with the batch assembled on the GPU; consumes the NumPy RNG exactly like get_data."""
         ro, rd, imgs, ks, es, feats, targets = [], [], [], [], [], [], []
         for i in batch:
             idx = np.random.choice(range(self.n_perspectives), size=self.n_views + 1, replace=False)
             src, tgt = idx[:-1], idx[-1]
-            color = self.dataset.colors[i][tgt]
-            cam = self.dataset.cameras[i][tgt]
-            rays = bbox_biased_sample(self.n_rays_train, np.array([0, 0, color.shape[0], color.shape[1]]), color.shape[0], color.shape[1])
-            k = np.reshape(cam['intrinsics'], (3, 3)).astype(np.float32)
-            m = cam['pose'][:3, :3] @ np.linalg.inv(k)                                    # as generate_rays (host LAPACK)
-            px = torch.from_numpy(np.ascontiguousarray(rays)).to(dev)                      # (n,2) int64 (row, col)
-            r_o, r_d = ops.get_rays_device(m, cam['pose'][:3, -1], dev, u=px[:, 1].to(torch.float32).contiguous(),
-                                           v=px[:, 0].to(torch.float32).contiguous())
-            tgt_color = self._view(i, tgt)[1]
-            targets.append(tgt_color[px[:, 0], px[:, 1]].to(torch.float32) / 255.0)
+            r_d, r_o, px = self.generate_rays_device(self.dataset.colors[i][tgt], self.dataset.cameras[i][tgt])
+            targets.append(self.get_target_device(self._view(i, tgt)[1], px))
             views = [self._view(i, s_) for s_ in src]
             ro.append(r_o)
             rd.append(r_d)
