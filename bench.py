@@ -5,6 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a child
+`torch.distributed.run`, spawned before this process touches the GPU or loads the HIP library) and relays rank 0's line.
+
 One "step" = one full `_call` (model_v0.py:113-184) over one batch of synthetic rays: stratified
 depths -> coarse field (64 samples/ray) -> composite -> resample -> fine field (128 samples/ray) ->
 composite.  Workload at every N: BASELINE.json configs[1] as restated in SURVEY.md 8d (cfg2):
@@ -12,36 +15,75 @@ B=1 scene, V=1 source view of 64x64 (3+256 channels), R=4096 rays (every pixel o
 view), fp32, inputs resident in HBM before the timed region.  N>1: every rank renders its own
 scene (rays/scenes are independent units, no data-path collective) -> weak scaling.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (field_eval_kernel, fp32
-MFMA bound): algorithmic FLOPs per launch (491 264 FLOP/sample) / its average
-duration measured with HIP events inside the timed region, against the 157.3 TFLOP/s fp32 MFMA
-peak.  `cpu_baseline` times the NumPy oracle (a port of the reference's TF graph; the reference
-itself cannot run here) on a bounded sample of the same rays on the host cores.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (field_eval_kernel, fp32 MFMA bound): the FLOPs the
+launch EXECUTES on the matrix pipe (tiles x MFMAs per 32-sample tile x 4096 FLOP per v_mfma_f32_32x32x2_f32; the count
+is checked against SQ_INSTS_VALU_MFMA_MOPS_F32 in profiles/) / its average duration measured with HIP events inside the
+timed region, against the 157.3 TFLOP/s fp32 MFMA peak; SURVEY.md 8d's algorithmic figure (491 264 FLOP/sample) over the
+same duration is reported beside it as `frac_reference_equiv`.  `cpu_baseline` times the op-for-op torch-CPU restatement
+of the reference's TF graph (oracle/mvnerf_torch.py, fp32; the reference itself cannot run here) on all 4096 rays on the
+host cores; `parity` checks the GPU result against the NumPy oracle on all 4096 rays.  `train_cfg4` is the data-parallel
+training leg (BASELINE.json configs[3]): one 128x128 scene = 16 384 rays per GPU, forward with stash + backward + ONE
+flat all-reduce of the 494 600 gradients + clip + Adam.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from thesis_clip_nerf_amd import ops  # noqa: E402
-from thesis_clip_nerf_amd.distributed import max_over_ranks  # noqa: E402
-from thesis_clip_nerf_amd.synthetic import make_scene  # noqa: E402
-
 FLOP_PER_SAMPLE_V1 = 491264          # BASELINE.md 3 (2 x 245 632 MAC), one source view
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md, chip-level parameters
+METRIC = 'rendered rays/sec (64 samples/ray) at 1/2/4/8 MI355X; RGB L1 vs ref'
 
 
-def flop_per_sample(v, table=False):
-    """MFMA FLOPs per sample: per view Dense 379->128 + 3 blocks, then 3 blocks + read-out.  With the texel table the
-    256 feature rows of layer 0 are not multiplied per sample (they are per texel, in project_texels_kernel)."""
-    return 2 * (v * ((379 - (256 if table else 0)) * 128 + 6 * 128 * 128) + 6 * 128 * 128 + 128 * 4)
+def reference_flop_per_sample(v):
+    """per view Dense 379->128 + 3 blocks, then 3 blocks + read-out, 2 FLOP per MAC."""
+    return 2 * (v * (379 * 128 + 6 * 128 * 128) + 6 * 128 * 128 + 128 * 4)
+
+
+def mfma_per_tile(v, table, bf16=False):
+    """Matrix instructions one 32-sample tile issues: layer 0 streams K = 64 rows (PE(cam xyz) 60 + rgb 3,
+    padded; the 60 PE(cam dir) rows are a per-ray seed computed on the vector ALU) + 256 feature rows unless those come from
+    the texel table; 12 hidden layers of K = 128; the 128->4 read-out runs on the vector ALU.  One k-step covers K = 2 (fp32
+    32x32x2) for each of the 4 output blocks of 32 features."""
+    if bf16:       # field_eval_bf16.hip: K = 16 per MFMA; direct form streams PE(xyz) 64 + PE(dir) 64 + 256 feature rows, the table
+        #            form 64 rows (PE(dir) in the per-ray seed, features from the table); read-out = 2 k-steps x 4 blocks on the MFMA
+        l0 = (64 if table else 384) // 16 * 4
+        return v * (l0 + 6 * 32) + 6 * 32 + 8
+    l0 = (64 + (0 if table else 256)) // 2 * 4
+    hidden = 128 // 2 * 4
+    return v * (l0 + 6 * hidden) + 6 * hidden
+
+
+def flop_per_mfma(bf16=False):
+    return 2 * 32 * 32 * (16 if bf16 else 2)
+
+
+def self_launch(args):
+    """N > 1 without a launcher: start the ranks as a child process tree.  Nothing in this process has touched the GPU or
+    loaded libmvnerf_hip.so yet (no exec of a GPU-initialised process, no GPU context in the parent)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return proc.returncode if proc.returncode != 0 or line is not None else 1
 
 
 def main():
@@ -54,14 +96,23 @@ def main():
     ap.add_argument('--height', type=int, default=0, help='source image height (default: --size)')
     ap.add_argument('--width', type=int, default=0, help='source image width (default: --size)')
     ap.add_argument('--rays', type=int, default=0, help='random target pixels instead of every pixel of a size x size view (e.g. cfg5: 16384 rays, 480x640 sources)')
-    ap.add_argument('--cpu-rays', type=int, default=512, help='rays of the bounded CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cpu-baseline', default='on', choices=['on', 'off'], help='N=1: time the torch-CPU restatement and check parity on all rays')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='bf16: both field passes on the bf16 MFMA kernel (configs 3/5; not the headline)')
     ap.add_argument('--texel-table', default='auto', choices=['auto', 'on', 'off'],
                     help="hoist layer 0's feature rows to a per-texel table rebuilt every step (auto: when R*S >= 2*H*W)")
     ap.add_argument('--train-steps', type=int, default=5,
-                    help='N=1 only: also time this many train_step calls (fwd + bwd + clip + Adam) on the same scene, reported as an extra object (0 = skip)')
+                    help='timed train_step calls of the two training legs (cfg2 scene at N=1; cfg4 128x128 scene per GPU with the gradient all-reduce at every N); 0 = skip')
     ap.add_argument('--fused-call', action='store_true', help='time mvnerf_render_fwd (one C call) instead of the op sequence')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
+
+    import numpy as np
+    import torch
+    from thesis_clip_nerf_amd import ops
+    from thesis_clip_nerf_amd.distributed import max_over_ranks
+    from thesis_clip_nerf_amd.synthetic import make_scene
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -73,6 +124,7 @@ def main():
     dev_index = local_rank if backend == 'nccl' else local_rank % max(n_dev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -138,14 +190,15 @@ def main():
         out = step(ev[i])
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, dev if backend == 'nccl' else 'cpu')   # the slowest rank's clock (no-op at world 1)
+    red_dev = dev if backend == 'nccl' else 'cpu'
+    elapsed = max_over_ranks(elapsed, red_dev)   # the slowest rank's clock (no-op at world 1)
 
     rays_per_step = b * r * world
     ms_per_step = 1e3 * elapsed / args.steps
     value = rays_per_step * args.steps / elapsed
 
     result = {
-        'metric': 'rendered rays/sec (64 samples/ray)', 'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
+        'metric': METRIC, 'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': f'cfg2: _call on B=1 scene/GPU, V={args.views} source view {img_h}x{img_w}x(3+256) fp32, '
@@ -156,55 +209,66 @@ def main():
                    'rays_per_gpu': b * r, 'samples_per_ray': [s, 2 * s], 'n_views': args.views,
                    'call': 'mvnerf_render_fwd' if args.fused_call else f'op sequence ({7 if use_table else 6} C-ABI calls/step)',
                    'layer0_features': 'texel table, rebuilt every step' if use_table else 'gathered per sample',
-                   'parallelism': f'ray/scene sharding x{world}, no data-path collective'},
+                   'parallelism': f'ray/scene sharding x{world}, no data-path collective',
+                   'launcher': 'torch.distributed.run' if world > 1 else 'single process'},
     }
 
-    if rank == 0:
-        fps = flop_per_sample(args.views, use_table)
-        fps_ref = flop_per_sample(args.views)
-        if not args.fused_call:
-            coarse_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-            fine_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
-            flops_c, flops_f = fps * b * r * s, fps * b * r * 2 * s
-            # the fine-pass launch is the dominant kernel instance (2/3 of the FLOPs)
-            achieved = flops_f / (fine_ms * 1e-3) / 1e12
-            peak = 2500.0 if bf16 else PEAK_FP32_MFMA_TFLOPS          # dense bf16 MFMA peak ~2.5 PFLOP/s
-            kname = (('field_eval_bf16_kernel' if bf16 else 'field_eval_kernel') + ('<true' if args.views > 1 else '<false') +
-                     ((',true>' if use_table else ',false>') if bf16 else (',false,true>' if use_table else ',false,false>')))
-            result['roofline'] = {
-                'bound': 'mfma', 'kernel': kname + ' (fine pass, S=128)',
-                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                'traffic': None, 'flop_per_launch': flops_f, 'avg_launch_ms': fine_ms,
-                'coarse_launch': {'flop_per_launch': flops_c, 'avg_launch_ms': coarse_ms,
-                                  'achieved': flops_c / (coarse_ms * 1e-3) / 1e12},
-                'field_kernel_share_of_step': (coarse_ms + fine_ms) / ms_per_step,
-                # the literal '64 samples/ray' reading of the metric = the coarse pass alone
-                'coarse_only_rays_per_sec': b * r / (coarse_ms * 1e-3),
-            }
-            if use_table:
-                # `achieved` counts the FLOPs the kernel executes; the reference's graph multiplies the 256 feature
-                # rows per sample, so the same launch stands for more "reference FLOPs" than it runs
-                result['roofline']['reference_flop_per_launch'] = fps_ref * b * r * 2 * s
-                result['roofline']['reference_equiv_tflops'] = fps_ref * b * r * 2 * s / (fine_ms * 1e-3) / 1e12
-                # SURVEY.md 8d's algorithmic figure (491 264 FLOP/sample at V=1) over the same duration; > 1 is possible because
-                # 13 % of those FLOPs are not executed per sample any more - `frac` above is the hardware utilisation
-                result['roofline']['frac_reference_equiv'] = result['roofline']['reference_equiv_tflops'] / peak
-                result['roofline']['project_texels_ms_per_step'] = float(np.mean([e[4].elapsed_time(e[5]) for e in ev]))
-            pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-            if os.path.exists(pmc) and not bf16 and args.views == 1 and (img_h, img_w, r) == (64, 64, 4096):   # counters were collected on cfg2
-                try:
-                    key = 'field_eval_table_fine_hbm_bytes_per_launch' if use_table else 'field_eval_fine_hbm_bytes_per_launch'
-                    counters = json.load(open(pmc))
-                    result['roofline']['traffic'] = counters.get(key)
-                    if counters.get(key):                  # rocprof counters (profiles/): HBM-side GB/s of this launch, matrix pipe busy
-                        result['roofline']['hbm_gbps_from_pmc_traffic'] = counters[key] / (fine_ms * 1e-3) / 1e9
-                        result['roofline']['mfma_busy_pmc'] = counters.get(key.replace('hbm_bytes_per_launch', 'mfma_busy'))
-                except Exception:
-                    pass
-        if world == 1 and args.train_steps > 0 and not bf16:
+    if rank == 0 and not args.fused_call:
+        coarse_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        fine_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+        n_tiles_c, n_tiles_f = (b * r * s + 31) // 32, (b * r * 2 * s + 31) // 32
+        mpt = mfma_per_tile(args.views, use_table, bf16)
+        fpm = flop_per_mfma(bf16)
+        flops_c, flops_f = n_tiles_c * mpt * fpm, n_tiles_f * mpt * fpm
+        fps_ref = reference_flop_per_sample(args.views)
+        # the fine-pass launch is the dominant kernel instance (2/3 of the FLOPs)
+        achieved = flops_f / (fine_ms * 1e-3) / 1e12
+        peak = 2500.0 if bf16 else PEAK_FP32_MFMA_TFLOPS          # dense bf16 MFMA peak ~2.5 PFLOP/s
+        kname = (('field_eval_bf16_kernel' if bf16 else 'field_eval_kernel') + ('<true' if args.views > 1 else '<false') +
+                 ((',true>' if use_table else ',false>') if bf16 else (',false,true>' if use_table else ',false,false>')))
+        ref_tflops = fps_ref * b * r * 2 * s / (fine_ms * 1e-3) / 1e12
+        result['roofline'] = {
+            'bound': 'mfma', 'kernel': kname + ' (fine pass, S=128)',
+            'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+            'traffic': None, 'flop_per_launch': flops_f, 'avg_launch_ms': fine_ms,
+            'flop_count': f'executed on the matrix pipe: {n_tiles_f} tiles x {mpt} MFMAs x {fpm} FLOP',
+            'tiles_per_launch': n_tiles_f, 'mfma_per_tile': mpt,
+            'coarse_launch': {'flop_per_launch': flops_c, 'avg_launch_ms': coarse_ms,
+                              'achieved': flops_c / (coarse_ms * 1e-3) / 1e12},
+            'field_kernel_share_of_step': (coarse_ms + fine_ms) / ms_per_step,
+            # the literal '64 samples/ray' reading of the metric = the coarse pass alone
+            'coarse_only_rays_per_sec': b * r / (coarse_ms * 1e-3),
+            # SURVEY.md 8d's algorithmic figure (491 264 FLOP/sample at V=1) over the same duration; it can exceed 1 because
+            # the PE(dir) rows are hoisted to a per-ray seed and, with the table, the feature rows to per-texel products
+            'reference_flop_per_launch': fps_ref * b * r * 2 * s,
+            'reference_equiv_tflops': ref_tflops, 'frac_reference_equiv': ref_tflops / peak,
+        }
+        if use_table:
+            result['roofline']['project_texels_ms_per_step'] = float(np.mean([e[4].elapsed_time(e[5]) for e in ev]))
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(pmc) and not bf16 and args.views == 1 and (img_h, img_w, r) == (64, 64, 4096):   # counters were collected on cfg2
+            try:
+                key = 'field_eval_table_fine_hbm_bytes_per_launch' if use_table else 'field_eval_fine_hbm_bytes_per_launch'
+                counters = json.load(open(pmc))
+                result['roofline']['traffic'] = counters.get(key)
+                if counters.get(key):                  # rocprof counters (profiles/): HBM-side GB/s of this launch, matrix pipe busy
+                    result['roofline']['hbm_gbps_from_pmc_traffic'] = counters[key] / (fine_ms * 1e-3) / 1e9
+                    result['roofline']['mfma_busy_pmc'] = counters.get(key.replace('hbm_bytes_per_launch', 'mfma_busy'))
+                    mops = counters.get(key.replace('hbm_bytes_per_launch', 'mfma_flop_per_launch_pmc'))
+                    if mops:
+                        result['roofline']['flop_per_launch_pmc'] = mops
+            except Exception:
+                pass
+
+    if args.train_steps > 0 and not bf16:
+        if world == 1:
             result['train_step'] = train_throughput(sc, t, args.views, dev, args.train_steps)
-        if world == 1 and args.cpu_rays > 0:
-            result['cpu_baseline'], result['parity'] = cpu_baseline(sc, out, args.cpu_rays)
+        leg = train_cfg4(rank, world, dev, backend, args.train_steps, barrier, red_dev)
+        if rank == 0:
+            result['train_cfg4'] = leg
+    if rank == 0:
+        if world == 1 and args.cpu_baseline == 'on' and (img_h, img_w) == (64, 64) and args.views == 1 and not args.rays:
+            result['cpu_baseline'], result['parity'] = cpu_baseline(sc, out)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -213,6 +277,7 @@ def main():
 def train_throughput(sc, t, n_views, dev, steps):
     """cfg2 'fwd+bwd rays/s' (SURVEY.md 8d): MVVNeRFRenderer.train_step (model_v0.py:186-197) = forward with stash,
     full backward (incl. the gradient through the importance samples), clip-by-value, Adam; not part of `value`."""
+    import torch
     from thesis_clip_nerf_amd import MVVNeRFRenderer
     r = t['rays_o'].shape[1]
     m = MVVNeRFRenderer(r, r, n_views=n_views, near=sc['near'], far=sc['far'], device=dev)
@@ -233,48 +298,161 @@ def train_throughput(sc, t, n_views, dev, steps):
             'what': 'train_step: fwd (activations stashed) + bwd of both nets incl. d/d(sample depth) + clip + Adam, fp32'}
 
 
-def cpu_baseline(sc, gpu_out, n_rays):
-    """Oracle (oracle/mvnerf_oracle.py, NumPy fp32 port of the TF graph) on the first `n_rays` rays of
-    the benchmark scene, on this box's host cores; also the checker for the GPU result on those rays."""
-    from oracle import mvnerf_oracle as O
-    try:
-        from threadpoolctl import threadpool_info
-        blas_threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
-    except Exception:
-        blas_threads = os.cpu_count()
-    cn, fn = O.unflatten_net(sc['coarse']), O.unflatten_net(sc['fine'])
-    sl = slice(0, n_rays)
+def train_cfg4(rank, world, dev, backend, steps, barrier, red_dev):
+    """BASELINE.json configs[3] as restated in SURVEY.md 8d (cfg4): one scene per GPU, 128x128 source view, 16 384 rays (every
+    pixel of a 128x128 target), forward with stash + backward + ONE flat all-reduce (mean) of the 494 600 fp32 gradients of both
+    MLPs + clip + Adam (model_v0.py:186-197 per rank; the mean over ranks is the gradient of the `world`-scene batch).  Timed
+    like the main leg: barrier + synchronize on both sides, max over ranks; rays/s is the whole job's."""
+    import numpy as np
+    import torch
+    from thesis_clip_nerf_amd import MVVNeRFRenderer
+    from thesis_clip_nerf_amd.distributed import allreduce_mean_, max_over_ranks
+    from thesis_clip_nerf_amd.synthetic import make_scene
+    sc = make_scene(seed=1000 + rank, batch=1, n_views=1, height=128, width=128)
+    t = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in
+         ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'u_coarse', 'u_fine']}
+    r = t['rays_o'].shape[1]
+    m = MVVNeRFRenderer(r, r, n_views=1, near=sc['near'], far=sc['far'], device=dev, seed=0)        # same initial weights on every rank
+    m.compile(learning_rate=1e-4, grad_sync=allreduce_mean_ if world > 1 else None)
+    inputs = tuple(t[k] for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'])
+    y = torch.rand((1, r, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
+    kw = dict(combined_features=t['features'], u_coarse=t['u_coarse'], u_fine=t['u_fine'])
 
-    def run():
-        return O.render_call(cn, fn, sc['rays_o'][:, sl], sc['rays_d'][:, sl], sc['images'], sc['intrinsics'],
-                             sc['extrinsics_inv'], sc['features'], sc['near'], sc['far'], sc['n_samples'],
-                             sc['u_coarse'][:, sl], sc['u_fine'][:, sl])
-    run()                                   # warm-up (BLAS thread pool, page faults)
-    times = []
-    ref = None
-    for _ in range(3):
+    def timed(fn, n, warm):
+        for _ in range(warm):
+            fn()
+        barrier()
         t0 = time.perf_counter()
-        ref = run()
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
+        for _ in range(n):
+            fn()
+        barrier()
+        return max_over_ranks((time.perf_counter() - t0) / n, red_dev)
+
+    dt_fwd = timed(lambda: m.infer(inputs, t['features'], u_coarse=t['u_coarse'], u_fine=t['u_fine']), steps, 1)
+    dt_train = timed(lambda: m.train_step((inputs, y), **kw), steps, 2)
+    leg = {'workload': 'cfg4: B=1 scene/GPU, V=1 source view 128x128x(3+256) fp32, 16384 rays (all pixels), 64+128 samples/ray',
+           'rays_per_gpu': r, 'steps': steps,
+           'forward_rays_per_sec': world * r / dt_fwd, 'forward_ms_per_step': 1e3 * dt_fwd,
+           'train_rays_per_sec': world * r / dt_train, 'train_ms_per_step': 1e3 * dt_train,
+           'what': 'train_step = fwd (stash) + bwd of both nets incl. d/d(sample depth) + flat gradient all-reduce (mean) + clip + Adam, fp32'}
+    if world > 1:
+        buf = torch.zeros(2 * 247300, dtype=torch.float32, device=dev)
+        dt_ar = timed(lambda: allreduce_mean_(buf), 20, 3)
+        leg['allreduce_ms'] = 1e3 * dt_ar
+        leg['allreduce'] = f'one {buf.numel() * 4} B fp32 all-reduce per step ({backend}), {1e3 * dt_ar:.3f} ms = {dt_ar / dt_train:.1%} of the step'
+        # every rank must hold the same weights after the same averaged updates
+        chk = torch.stack([m.coarse_net.double().sum(), m.fine_net.double().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        import torch.distributed as dist
+        if backend != 'nccl':
+            lo, hi = lo.cpu(), hi.cpu()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        leg['weights_identical_across_ranks'] = bool(torch.equal(lo, hi))
+    return leg
+
+
+def host_cores():
+    """Threads the CPU baseline may use: physical cores visible to this process (SMT siblings collapsed), capped by the
+    scheduler affinity and a cgroup CPU quota if there is one."""
+    cores = set()
+    try:
+        phys = core = None
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.startswith('physical id'):
+                    phys = ln.split(':')[1].strip()
+                elif ln.startswith('core id'):
+                    core = ln.split(':')[1].strip()
+                elif not ln.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    n_phys = len(cores) or (os.cpu_count() or 1)
+    n_aff = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            quota = max(1, int(float(q) / float(p)))
+    except (OSError, ValueError):
+        pass
+    n = min(n_phys, n_aff, quota or n_phys)
+    return max(1, n), {'physical_cores': n_phys, 'affinity': n_aff, 'cgroup_quota': quota, 'logical': os.cpu_count()}
+
+
+def cpu_baseline(sc, gpu_out):
+    """SURVEY.md 8d / BASELINE.md 4: the reference cannot run here (TensorFlow), so "the reference CPU path" is the op-for-op,
+    unfused torch-CPU restatement of its graph (oracle/mvnerf_torch.py: separate gather, PE, 13 GEMMs per pass, cumprod, the
+    63-step compare-accumulate of sample_pdf), fp32, torch.set_num_threads(physical cores), on ALL rays of the benchmark scene:
+    forward (2 warm-ups, median of 5) and forward + backward of the training loss (1 warm-up, median of 3).  `parity` compares
+    the GPU result with the NumPy oracle (oracle/mvnerf_oracle.py, the arithmetic contract) on all rays."""
+    import numpy as np
+    import torch
+    from oracle import mvnerf_oracle as O
+    from oracle import mvnerf_torch as T
+    n_threads, core_info = host_cores()
+    torch.set_num_threads(n_threads)
+    n_rays = sc['rays_o'].shape[1]
+    tt = lambda k: torch.as_tensor(np.asarray(sc[k])).to(torch.float32)
+    args = [tt(k) for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv', 'features']]
+    uc, uf = tt('u_coarse'), tt('u_fine')
+
+    def fwd(cf, ff):
+        return T.render_call(cf, ff, *args, sc['near'], sc['far'], sc['n_samples'], uc, uf, unfused=True)
+
+    def run_fwd():
+        with torch.no_grad():
+            return fwd(tt('coarse'), tt('fine'))
+
+    y = torch.rand((1, n_rays, 3), generator=torch.Generator().manual_seed(0))
+
+    def run_train():
+        cf, ff = tt('coarse').requires_grad_(True), tt('fine').requires_grad_(True)
+        out = fwd(cf, ff)
+        (((y - out[0]) ** 2).mean() + ((y - out[2]) ** 2).mean()).backward()
+        return cf.grad, ff.grad
+
+    def median_time(fn, warm, n):
+        for _ in range(warm):
+            res = fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            res = fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), res
+
+    t_fwd, twin = median_time(run_fwd, 2, 5)
+    t_train, _ = median_time(run_train, 1, 3)
     cpu_model = 'unknown'
     try:
         with open('/proc/cpuinfo') as f:
-            cpu_model = next((l.split(':', 1)[1].strip() for l in f if l.startswith('model name')), 'unknown')
+            cpu_model = next((ln.split(':', 1)[1].strip() for ln in f if ln.startswith('model name')), 'unknown')
     except OSError:
         pass
-    base = {'value': n_rays / med, 'unit': 'rays/s', 'cores': int(blas_threads), 'kind': 'port', 'cpu_model': cpu_model,
-            'sample': f'first {n_rays} of the 4096 rays of the same scene, full 64+128 samples, NumPy fp32 oracle '
-                      f'(op-for-op port of the TF graph; BLAS sgemm uses {blas_threads} threads, the rest is single-threaded), '
-                      f'median of 3 after 1 warm-up, {med:.2f} s per run; host has {os.cpu_count()} logical cores'}
+    base = {'value': n_rays / t_fwd, 'unit': 'rays/s', 'cores': n_threads, 'kind': 'port', 'cpu_model': cpu_model,
+            'forward_s': t_fwd, 'train_rays_per_sec': n_rays / t_train, 'train_s': t_train, 'host': core_info,
+            'sample': f'all {n_rays} rays of the same scene, full 64+128 samples: op-for-op torch-CPU restatement of the TF graph '
+                      f'(oracle/mvnerf_torch.py, fp32, unfused, 63-step compare-accumulate in sample_pdf), torch.set_num_threads({n_threads}); '
+                      f'forward: median of 5 after 2 warm-ups = {t_fwd:.2f} s; forward+backward of the training loss: median of 3 after 1 '
+                      f'warm-up = {t_train:.2f} s'}
+    # parity: the NumPy oracle on all rays
+    cn, fn = O.unflatten_net(sc['coarse']), O.unflatten_net(sc['fine'])
+    ref = O.render_call(cn, fn, sc['rays_o'], sc['rays_d'], sc['images'], sc['intrinsics'], sc['extrinsics_inv'], sc['features'],
+                        sc['near'], sc['far'], sc['n_samples'], sc['u_coarse'], sc['u_fine'])
     names = ['rgb', 'depth', 'fine_rgb', 'fine_depth']
     parity = {}
-    for n, g, rf in zip(names, gpu_out, ref):
-        diff = np.abs(g.cpu().numpy()[:, sl] - rf)
+    for n, g, rf, tw in zip(names, gpu_out, ref, twin):
+        diff = np.abs(g.cpu().numpy() - rf)
         parity[n + '_max_abs'] = float(diff.max())
         parity[n + '_mean_l1'] = float(diff.mean())
+        parity[n + '_max_abs_vs_torch_cpu'] = float(np.abs(g.cpu().numpy() - tw.numpy()).max())
     parity['checked_rays'] = n_rays
     parity['tolerance'] = 1e-4
+    parity['oracle'] = 'oracle/mvnerf_oracle.py (NumPy fp32); *_vs_torch_cpu: the timed torch-CPU restatement'
     return base, parity
 
 

@@ -140,7 +140,10 @@ def volumetric_render(zs, density, chroma):
     return (w[..., None] * chroma).sum(-2), (w * zs).sum(-1), w
 
 
-def sample_pdf(bins, weights, u, q7_zero=True):
+def sample_pdf(bins, weights, u, q7_zero=True, unfused=False):
+    """nerf_utils.py:143-176.  unfused=True keeps the reference's op granularity for the CPU-baseline timing:
+    `above` by the 63-step compare-accumulate of the tf.scan (:153-160) instead of one broadcast compare, cdf / bins
+    materialised n_samples times (`repeat`, :163,167) before the four gathers.  Same values either way."""
     stable = weights + 1e-5
     w_sum = stable.sum(-1, keepdim=True)
     w_sum = torch.where(w_sum.abs() == 0, torch.ones_like(w_sum), w_sum)
@@ -148,12 +151,28 @@ def sample_pdf(bins, weights, u, q7_zero=True):
     cdf = torch.cumsum(pdf, -1)
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
     nb = bins.shape[-1]
-    above = (u[..., None] >= cdf[..., None, :]).sum(-1)
+    if unfused:
+        above = torch.zeros(u.shape, dtype=torch.int32)
+        for j in range(cdf.shape[-1]):
+            above = above + (u >= cdf[..., j:j + 1]).to(torch.int32)
+        above = above.to(torch.int64)
+    else:
+        above = (u[..., None] >= cdf[..., None, :]).sum(-1)
     below = torch.clamp(above - 1, 0, nb - 1)
 
-    def gather(tab, idx):
-        val = torch.gather(tab, -1, torch.clamp(idx, max=nb - 1))
-        return torch.where(idx >= nb, torch.zeros_like(val), val) if q7_zero else val
+    if unfused:
+        n = u.shape[-1]
+        cdf_rep = cdf[..., None, :].repeat(1, 1, n, 1)
+        bins_rep = bins[..., None, :].repeat(1, 1, n, 1)
+
+        def gather(tab, idx):
+            rep = cdf_rep if tab is cdf else bins_rep
+            val = torch.gather(rep, -1, torch.clamp(idx, max=nb - 1)[..., None])[..., 0]
+            return torch.where(idx >= nb, torch.zeros_like(val), val) if q7_zero else val
+    else:
+        def gather(tab, idx):
+            val = torch.gather(tab, -1, torch.clamp(idx, max=nb - 1))
+            return torch.where(idx >= nb, torch.zeros_like(val), val) if q7_zero else val
 
     cdf_a, cdf_b = gather(cdf, above), gather(cdf, below)
     bins_a, bins_b = gather(bins, above), gather(bins, below)
@@ -193,14 +212,15 @@ def query_acts(net, points, dirs, images, features, k4, einv):
 
 
 def render_call(coarse_flat, fine_flat, o, d, images, k4, einv, features, near, far, n_samples, u_coarse, u_fine,
-                stop_fine_z=False, q7_zero=True):
-    """model_v0.py:113-184 -> (rgb, depth, fine_rgb, fine_depth); differentiable w.r.t. the flat nets."""
+                stop_fine_z=False, q7_zero=True, unfused=False):
+    """model_v0.py:113-184 -> (rgb, depth, fine_rgb, fine_depth); differentiable w.r.t. the flat nets.
+    unfused: sample_pdf at the reference's op granularity (bench.py cpu_baseline)."""
     cn, fn = unflatten_net(coarse_flat), unflatten_net(fine_flat)
     _, z = sample_along_ray(o, d, near, far, n_samples, u_coarse)
     c_rgb, c_sigma = field_eval(cn, o, d, z, images, features, k4, einv)
     rgb, depth, weights = volumetric_render(z, c_sigma, c_rgb)
     z_mid = 0.5 * (z[..., 1:] + z[..., :-1])
-    z_fine = sample_pdf(z_mid, weights[..., 1:-1], u_fine, q7_zero)
+    z_fine = sample_pdf(z_mid, weights[..., 1:-1], u_fine, q7_zero, unfused)
     all_zs = torch.sort(torch.cat([z, z_fine], -1), -1).values
     if stop_fine_z:
         all_zs = all_zs.detach()

@@ -25,7 +25,9 @@ def test_product_does_not_import_oracle():
 def test_bench_uses_oracle_only_in_cpu_baseline():
     text = open(os.path.join(ROOT, 'bench.py')).read()
     hits = [m.start() for m in re.finditer(r'from oracle|import oracle', text)]
-    assert len(hits) == 1 and text.rfind('def cpu_baseline', 0, hits[0]) != -1
+    start = text.index('def cpu_baseline')
+    end = text.index("if __name__ == '__main__'")
+    assert hits and all(start < h < end for h in hits)       # the NumPy oracle and its torch twin, inside cpu_baseline() only
 
 
 def test_runtime_code_does_not_read_reference():

@@ -279,6 +279,11 @@ class MVVNeRFRenderer:
             loss, grad, _ = self.loss_and_grads(inputs, labels, combined_features, u_coarse, u_fine, generator, stop_fine_z)
         if self._grad_sync is not None:
             self._grad_sync(grad)                         # one flat collective for both MLPs
+        self.apply_gradients(grad)
+        return {'loss': loss}
+
+    def apply_gradients(self, grad):
+        """optimize() (nerf_utils.py:8-12) on the flat gradient [coarse | fine]: clip-by-value, Adam (tf.keras, eps 1e-7)."""
         o = self._opt
         # Keras evaluates the schedule at `optimizer.iterations` BEFORE the increment (0 on the first step: the warm-up's
         # first update has lr = 0); only the Adam bias correction uses iterations + 1
@@ -290,7 +295,6 @@ class MVVNeRFRenderer:
             ops.adam_clip(net, grad[sl], self._adam_m[sl], self._adam_v[sl], lr_t, o['b1'], o['b2'], o['eps'], o['clip'],
                           self._update_mask[sl])
         self.weights_changed()
-        return {'loss': loss}
 
     # ---- checkpoint (model_v0.py:199-240; per-sub-model files, load() -> False if any is missing) ----
     def _split(self, flat):
