@@ -81,11 +81,15 @@ def test_cfg5_fp32_render_matches_oracle_and_is_ray_independent(cfg5):
             print(f'cfg5 fp32 {tag} {name}: max|hip - oracle| over 256 rays = {err:.2e}')
             assert err < 1e-4, (name, tag, err)                              # north_star: rendered RGB within 1e-4 in fp32
         assert (got_t - got_d).abs().max().item() < 2e-5, name              # fp32 re-association of layer 0 only
-    again = _render(d, tables='auto')
-    lo, hi = _render(d, slice(0, 5000), 'auto'), _render(d, slice(5000, 16384), 'auto')   # ragged tile at the cut
-    for w_, a_, l_, h_ in zip(whole, again, lo, hi):
-        assert torch.equal(w_, a_)                                          # deterministic
-        assert torch.equal(w_, torch.cat([l_, h_], 1))                      # rays are independent units
+    # determinism and ray independence (the cut leaves a ragged 32-sample tile), on the direct path and on the table path - the
+    # latter with the tables forced, since 'auto' would build none for the smaller part (R*S < 2*H*W there)
+    forced = torch.empty((2, 1, 3, 480, 640, 128), dtype=torch.float32, device=DEV)
+    for tables, ref_out in ((None, direct), (forced, whole)):
+        again = _render(d, tables=tables)
+        lo, hi = _render(d, slice(0, 5001), tables), _render(d, slice(5001, 16384), tables)
+        for w_, a_, l_, h_ in zip(ref_out, again, lo, hi):
+            assert torch.equal(w_, a_)                                      # deterministic
+            assert torch.equal(w_, torch.cat([l_, h_], 1))                  # rays are independent units
 
 
 def test_cfg5_tap_indices_and_sample_indices_bit_exact(cfg5):
@@ -176,6 +180,20 @@ def _oracle_acts_fn(sc, d, bi):
     return lambda p, q: torch.stack(T.query_acts(net, p, q, *geo), 0), t64
 
 
+def _oracle_acts_np(sc, feats_bi, bi, points, dirs):
+    """The NumPy fp32 oracle (the arithmetic contract: fp32 pixel coordinates and lerp factors) on query points of scene `bi`:
+    project -> gather -> PE -> trunk with complete_output, as lmvnerf/model_v4.py:216-262 -> the 8 activations."""
+    sl = slice(bi, bi + 1)
+    world = points[:, :, None, :]                                            # one "sample" per point
+    pix, cam = O.compute_pixel_in_image_mv(world, sc['intrinsics'][sl], sc['extrinsics_inv'][sl])
+    norm = (sc['images'][sl] * np.float32(2.0) - np.float32(1.0)).astype(np.float32)
+    feat = O.get_projection_features_mv(norm, feats_bi, pix)
+    cdir = O.world_to_camera_direction_vector_mv(dirs, sc['extrinsics_inv'][sl])[:, :, :, None, :]
+    n = points.shape[1]
+    return O.mv_embedding(O.unflatten_net(sc['fine']), cam[..., :3].reshape(1, n, 1, 3), cdir.reshape(1, n, 1, 3),
+                          feat.reshape(1, n, 1, -1), 1, complete_output=True)
+
+
 def test_cfg3_query_field_bf16_and_fp32_at_full_size(cfg3):
     sc, d, points, dirs = cfg3
     geo = (d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'])
@@ -193,11 +211,19 @@ def test_cfg3_query_field_bf16_and_fp32_at_full_size(cfg3):
         assert err.mean().item() < 2e-2 * ref.abs().mean().item() and torch.isfinite(fused16[k]).all()
     sub = np.arange(0, 8064, 126)                                            # 64 points of the first and of the last scene
     for bi in (0, 7):
+        want = _oracle_acts_np(sc, d['features'][bi:bi + 1].cpu().numpy(), bi, points[bi:bi + 1, sub], dirs[bi:bi + 1, sub])
+        for k in range(8):                                                   # x0, f1..f3 (per view, V = 1), mean, u1..u3
+            got = acts[k][bi, sub].cpu().numpy()
+            err = np.abs(got - want[k][0, :, 0]).max()
+            assert err < 2e-5 * max(1.0, np.abs(want[k]).max()), (bi, k, err)
+        # the float64 twin differs from both by fp32 input rounding (the top positional-encoding octave's argument, ~1.6e3 rad,
+        # carries 1e-4; the pixel coordinate, |x| up to 640, 4e-5 in the lerp factor on white-noise feature maps): a looser,
+        # independent cross-check of the same activations
         f, t64 = _oracle_acts_fn(sc, d, bi)
-        want = f(t64(points[bi:bi + 1, sub]), t64(dirs[bi:bi + 1, sub])).numpy()           # (4,1,64,128)
+        want64 = f(t64(points[bi:bi + 1, sub]), t64(dirs[bi:bi + 1, sub])).numpy()         # (4,1,64,128)
         for k in range(4):
             got = acts[4 + k][bi, sub].cpu().numpy()
-            assert np.abs(got - want[k, 0]).max() < 2e-5 * max(1.0, np.abs(want[k]).max()), (bi, k)
+            assert np.abs(got - want64[k, 0]).max() < 1e-3 * max(1.0, np.abs(want64[k]).max()), (bi, k)
     # ray (here: point) independence at this size: the second half alone equals the second half of the whole
     _, acts_hi = ops.query_field(d['points'][:, 4000:].contiguous(), d['dirs'][:, 4000:].contiguous(), *geo, d['pf'], complete_output=True)
     for k in range(4, 8):
@@ -217,12 +243,20 @@ def test_cfg3_query_vjp_jvp_at_full_size(cfg3):
     dp, dd = ops.query_vjp(d['points'], d['dirs'], *geo, ops.pack_bwd_streams(d['fine']), stash, g)
     torch.cuda.synchronize()
     assert torch.isfinite(t_acts).all() and torch.isfinite(dp).all() and torch.isfinite(dd).all()
-    # <g, J t> = <J^T g, t>, scene by scene (a wrong scene offset cannot hide in the total)
+    # <g, J t> = <J^T g, t>, point by point (a wrong scene offset cannot hide in a total).  The two HIP paths evaluate the
+    # primal in different kernels, so a pre-activation within rounding of zero may take the other relu branch in one of them,
+    # which changes that point's Jacobian: a handful of the 64 512 points may disagree, all others must agree tightly.
+    lhs = (t_acts.double() * g.double()).sum(dim=(0, 3))                                    # (8, 8064)
+    rhs = (dp.double() * tp.double()).sum(-1) + (dd.double() * td.double()).sum(-1)
+    scale = lhs.abs().median().item()
+    bad = (lhs - rhs).abs() > 1e-3 * torch.maximum(torch.maximum(lhs.abs(), rhs.abs()), torch.tensor(scale, device=DEV))
     for bi in range(8):
-        lhs = float((t_acts[:, bi].double() * g[:, bi].double()).sum())
-        rhs = float((dp[bi].double() * tp[bi].double()).sum() + (dd[bi].double() * td[bi].double()).sum())
-        print(f'cfg3 scene {bi}: <g,Jt> = {lhs:.6e}, <JTg,t> = {rhs:.6e}')
-        assert abs(lhs - rhs) < 1e-3 * max(abs(lhs), abs(rhs), 1.0), (bi, lhs, rhs)
+        print(f'cfg3 scene {bi}: <g,Jt> = {lhs[bi].sum().item():.6e}, <JTg,t> = {rhs[bi].sum().item():.6e}, '
+              f'points off by > 1e-3: {int(bad[bi].sum())} of 8064')
+        assert int(bad[bi].sum()) <= 8, (bi, int(bad[bi].sum()))                           # < 0.1 % (relu flips)
+    good = ~bad
+    tot_l, tot_r = lhs[good].sum().item(), rhs[good].sum().item()
+    assert abs(tot_l - tot_r) < 1e-4 * lhs[good].abs().sum().item(), (tot_l, tot_r)
     # and against float64 autograd on 64 points of the last scene
     sub = np.arange(0, 8064, 126)
     f, t64 = _oracle_acts_fn(sc, d, 7)
