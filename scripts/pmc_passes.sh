@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 run() {  # name, counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python bench.py --steps 3 --warmup 1 --cpu-rays 0 "${BENCH_ARGS[@]}" > "$OUT/$name.log" 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python bench.py --steps 3 --warmup 1 --cpu-baseline off --train-steps 0 "${BENCH_ARGS[@]}" > "$OUT/$name.log" 2>&1
   echo "$name rc=$?"
 }
 BENCH_ARGS=("$@")
