@@ -45,11 +45,13 @@ def reference_flop_per_sample(v):
     return 2 * (v * (379 * 128 + 6 * 128 * 128) + 6 * 128 * 128 + 128 * 4)
 
 
-def mfma_per_tile(v, table, bf16=False):
+def mfma_per_tile(v, table, bf16=False, split=False):
     """Matrix instructions one 32-sample tile issues: layer 0 streams K = 64 rows (PE(cam xyz) 60 + rgb 3,
     padded; the 60 PE(cam dir) rows are a per-ray seed computed on the vector ALU) + 256 feature rows unless those come from
     the texel table; 12 hidden layers of K = 128; the 128->4 read-out runs on the vector ALU.  One k-step covers K = 2 (fp32
     32x32x2) for each of the 4 output blocks of 32 features."""
+    if split:      # field_eval_split.hip: per k-step of 16 rows 4 output blocks x 6 products; PE(dir) in the per-ray seed
+        return 24 * (v * ((4 if table else 20) + 48) + 48) + 48
     if bf16:       # field_eval_bf16.hip: K = 16 per MFMA; direct form streams PE(xyz) 64 + PE(dir) 64 + 256 feature rows, the table
         #            form 64 rows (PE(dir) in the per-ray seed, features from the table); read-out = 2 k-steps x 4 blocks on the MFMA
         l0 = (64 if table else 384) // 16 * 4
@@ -98,6 +100,8 @@ def main():
     ap.add_argument('--rays', type=int, default=0, help='random target pixels instead of every pixel of a size x size view (e.g. cfg5: 16384 rays, 480x640 sources)')
     ap.add_argument('--cpu-baseline', default='on', choices=['on', 'off'], help='N=1: time the torch-CPU restatement and check parity on all rays')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='bf16: both field passes on the bf16 MFMA kernel (configs 3/5; not the headline)')
+    ap.add_argument('--f32-gemm', default='mfma_f32', choices=['mfma_f32', 'split_bf16'],
+                    help='fp32 Dense layers on the fp32 MFMA, or as six bf16 MFMAs per product on exactly split operands (fp32-grade, csrc/field_eval_split.hip)')
     ap.add_argument('--texel-table', default='auto', choices=['auto', 'on', 'off'],
                     help="hoist layer 0's feature rows to a per-texel table rebuilt every step (auto: when R*S >= 2*H*W)")
     ap.add_argument('--train-steps', type=int, default=5,
@@ -144,8 +148,11 @@ def main():
          ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'u_coarse', 'u_fine', 'coarse', 'fine']}
     pc, pf = ops.pack_net(t['coarse']), ops.pack_net(t['fine'])
     bf16 = args.dtype == 'bf16'
+    split = args.f32_gemm == 'split_bf16' and not bf16
     if bf16:
         pc16, pf16 = ops.pack_net_bf16(t['coarse']), ops.pack_net_bf16(t['fine'])
+    if split:
+        pcs, pfs = ops.pack_net_split(t['coarse']), ops.pack_net_split(t['fine'])
     b, r, s = t['u_coarse'].shape
     ws = torch.empty(ops.render_workspace_bytes(b, args.views, r, s), dtype=torch.uint8, device=dev)
     near, far = sc['near'], sc['far']
@@ -166,12 +173,14 @@ def main():
         z = ops.stratified_depths(t['u_coarse'], near, far)
         if e: e[0].record()
         rgbs_c = (ops.field_eval_bf16(t['rays_o'], t['rays_d'], z, *field_args, pc, pc16, texel_table=tab_c) if bf16 else
+                  ops.field_eval_split(t['rays_o'], t['rays_d'], z, *field_args, pc, pcs, texel_table=tab_c) if split else
                   ops.field_eval(t['rays_o'], t['rays_d'], z, *field_args, pc, texel_table=tab_c))
         if e: e[1].record()
         rgb, depth, w = ops.composite(z, rgbs_c)
         z_all = ops.resample(z, w, t['u_fine'])
         if e: e[2].record()
         rgbs_f = (ops.field_eval_bf16(t['rays_o'], t['rays_d'], z_all, *field_args, pf, pf16, texel_table=tab_f) if bf16 else
+                  ops.field_eval_split(t['rays_o'], t['rays_d'], z_all, *field_args, pf, pfs, texel_table=tab_f) if split else
                   ops.field_eval(t['rays_o'], t['rays_d'], z_all, *field_args, pf, texel_table=tab_f))
         if e: e[3].record()
         fine_rgb, fine_depth, _ = ops.composite(z_all, rgbs_f, return_weights=False)
@@ -181,7 +190,7 @@ def main():
         return ops.render_fwd(t['rays_o'], t['rays_d'], *field_args, pc, pf, t['u_coarse'], t['u_fine'], near, far,
                               workspace=ws, texel_tables=tables)
 
-    step = step_fused if (args.fused_call and not bf16) else step_ops
+    step = step_fused if (args.fused_call and not bf16 and not split) else step_ops
     for _ in range(args.warmup):
         out = step()
     barrier()
@@ -200,7 +209,7 @@ def main():
     result = {
         'metric': METRIC, 'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'f32_gemm': None if bf16 else args.f32_gemm,
         'config': {'workload': f'cfg2: _call on B=1 scene/GPU, V={args.views} source view {img_h}x{img_w}x(3+256) fp32, '
                                f'R={r} rays ({"random pixels" if args.rays else "all pixels"} of a {img_h}x{img_w} target), 64 coarse + 128 fine samples/ray, '
                                'two 247300-param ResNet-MLPs (379->128, 3+3 blocks), explicit uniforms',
@@ -217,15 +226,16 @@ def main():
         coarse_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         fine_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
         n_tiles_c, n_tiles_f = (b * r * s + 31) // 32, (b * r * 2 * s + 31) // 32
-        mpt = mfma_per_tile(args.views, use_table, bf16)
-        fpm = flop_per_mfma(bf16)
+        mpt = mfma_per_tile(args.views, use_table, bf16, split)
+        fpm = flop_per_mfma(bf16 or split)
         flops_c, flops_f = n_tiles_c * mpt * fpm, n_tiles_f * mpt * fpm
         fps_ref = reference_flop_per_sample(args.views)
         # the fine-pass launch is the dominant kernel instance (2/3 of the FLOPs)
         achieved = flops_f / (fine_ms * 1e-3) / 1e12
-        peak = 2500.0 if bf16 else PEAK_FP32_MFMA_TFLOPS          # dense bf16 MFMA peak ~2.5 PFLOP/s
-        kname = (('field_eval_bf16_kernel' if bf16 else 'field_eval_kernel') + ('<true' if args.views > 1 else '<false') +
-                 ((',true>' if use_table else ',false>') if bf16 else (',false,true>' if use_table else ',false,false>')))
+        peak = 2500.0 if (bf16 or split) else PEAK_FP32_MFMA_TFLOPS   # dense bf16 MFMA peak ~2.5 PFLOP/s
+        kname = (('field_eval_bf16_kernel' if bf16 else 'field_eval_split_kernel' if split else 'field_eval_kernel') +
+                 ('<true' if args.views > 1 else '<false') +
+                 ((',true>' if use_table else ',false>') if (bf16 or split) else (',false,true>' if use_table else ',false,false>')))
         ref_tflops = fps_ref * b * r * 2 * s / (fine_ms * 1e-3) / 1e12
         result['roofline'] = {
             'bound': 'mfma', 'kernel': kname + ' (fine pass, S=128)',
@@ -246,7 +256,7 @@ def main():
         if use_table:
             result['roofline']['project_texels_ms_per_step'] = float(np.mean([e[4].elapsed_time(e[5]) for e in ev]))
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(pmc) and not bf16 and args.views == 1 and (img_h, img_w, r) == (64, 64, 4096):   # counters were collected on cfg2
+        if os.path.exists(pmc) and not bf16 and not split and args.views == 1 and (img_h, img_w, r) == (64, 64, 4096):   # counters were collected on cfg2
             try:
                 key = 'field_eval_table_fine_hbm_bytes_per_launch' if use_table else 'field_eval_fine_hbm_bytes_per_launch'
                 counters = json.load(open(pmc))

@@ -138,6 +138,22 @@ int mvnerf_field_eval_bf16(const float* rays_o, const float* rays_d, const float
                            float* rgbs, int32_t* tap_idx, float* embedding, float* acts_fused, void* workspace,
                            mvnerf_stream_t stream);
 
+/* ---- fp32-grade field pass on the bf16 matrix pipe ("split3"): every fp32 GEMM operand is cut exactly into three
+ * bf16 pieces and a product is issued as the six bf16 MFMAs of order >= 2^-16 with fp32 accumulation; the dropped terms
+ * are <= 2^-24 relative, one fp32 rounding (csrc/field_eval_split.hip).  Same function, inputs, outputs and 1e-4 bar as
+ * mvnerf_field_eval / mvnerf_field_eval_table (model_v0.py:122-144 / :157-180) at 6/16 of the fp32 MFMA's matrix time. ---- */
+size_t mvnerf_packed_net_split_bytes(void);
+/* Keras-order fp32 MLP (see mvnerf_pack_net) -> three-piece bf16 operand stream.  packed_split: 16-byte aligned. */
+int mvnerf_pack_net_split(const float* net_keras, void* packed_split, mvnerf_stream_t stream);
+/* As mvnerf_field_eval (texel_table NULL) / mvnerf_field_eval_table, with the Dense kernels taken from packed_split
+ * (biases, the per-ray layer-0 seed and the texel table still come from the fp32 image packed_net).  Optional outputs
+ * as there: tap_idx, pix, embedding, acts_per_view, acts_fused. */
+int mvnerf_field_eval_split(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                            const float* features, const float* texel_table, const float* intrinsics, const float* extrinsics_inv,
+                            const float* packed_net, const void* packed_split, int B, int V, int R, int S, int H, int W,
+                            float* rgbs, int32_t* tap_idx, float* pix, float* embedding, float* acts_per_view, float* acts_fused,
+                            void* workspace, mvnerf_stream_t stream);
+
 /* MVVNeRFRenderer.volumetric_render (model_v0.py:89-100) with sigma_to_alpha (nerf_utils.py:129-140).
  * z (n_rays,S); rgbs (n_rays,S,4); S in {64,128,192,256}.
  * rgb (n_rays,3); depth (n_rays); weights (optional, may be NULL) (n_rays,S). */

@@ -208,6 +208,42 @@ int mvnerf_field_eval_bf16(const float* rays_o, const float* rays_d, const float
     return hip_status(mvnerf::launch_field_eval_bf16(p, packed16, static_cast<hipStream_t>(stream)), "mvnerf_field_eval_bf16");
 }
 
+size_t mvnerf_packed_net_split_bytes(void) { return mvnerf::packed_net_split_bytes(); }
+
+int mvnerf_pack_net_split(const float* net_keras, void* packed_split, mvnerf_stream_t stream) {
+    if (!net_keras || !packed_split) return fail(MVNERF_E_ARG, "mvnerf_pack_net_split: null pointer");
+    if (!aligned16(packed_split)) return fail(MVNERF_E_ALIGN, "mvnerf_pack_net_split: packed_split must be 16-byte aligned");
+    return hip_status(mvnerf::launch_pack_net_split(net_keras, packed_split, static_cast<hipStream_t>(stream)), "mvnerf_pack_net_split");
+}
+
+int mvnerf_field_eval_split(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                            const float* features, const float* texel_table, const float* intrinsics, const float* extrinsics_inv,
+                            const float* packed_net, const void* packed_split, int B, int V, int R, int S, int H, int W,
+                            float* rgbs, int32_t* tap_idx, float* pix, float* embedding, float* acts_per_view, float* acts_fused,
+                            void* workspace, mvnerf_stream_t stream) {
+    if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !packed_net || !packed_split || !rgbs || !workspace)
+        return fail(MVNERF_E_ARG, "mvnerf_field_eval_split: null pointer");
+    if (B <= 0 || V <= 0 || R <= 0 || S <= 0) return fail(MVNERF_E_ARG, "mvnerf_field_eval_split: B=%d V=%d R=%d S=%d", B, V, R, S);
+    if (H < 2 || W < 2) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_split: source image %dx%d, need H,W >= 2 (bilinear taps)", H, W);
+    const long total = (long)B * R * S;
+    if (total >= (1L << 31) || (long)B * V * H * W >= (1L << 31))
+        return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_split: B*R*S=%ld or B*V*H*W too large for int32 indices", total);
+    if (!aligned16(features) || !aligned16(packed_net) || !aligned16(packed_split) || !aligned16(rgbs) || !aligned16(workspace) ||
+        (texel_table && !aligned16(texel_table)) || (tap_idx && !aligned16(tap_idx)) || (embedding && !aligned16(embedding)) ||
+        (acts_per_view && !aligned16(acts_per_view)) || (acts_fused && !aligned16(acts_fused)))
+        return fail(MVNERF_E_ALIGN, "mvnerf_field_eval_split: features, packed nets, texel_table, rgbs, tap_idx, embedding, acts, workspace must be 16-byte aligned");
+    mvnerf::FieldParams p = {};
+    p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.images = images; p.features = features;
+    p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs; p.tap_idx = tap_idx; p.pix = pix;
+    p.embedding = embedding; p.acts_view = acts_per_view; p.acts_fused = acts_fused;
+    p.texel_table = texel_table;
+    p.dir_bias = static_cast<float*>(workspace);
+    p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W;
+    p.total = total;
+    p.n_tiles = (total + 31) / 32;
+    return hip_status(mvnerf::launch_field_eval_split(p, packed_split, static_cast<hipStream_t>(stream)), "mvnerf_field_eval_split");
+}
+
 int mvnerf_composite(const float* z, const float* rgbs, int n_rays, int S, float* rgb, float* depth, float* weights,
                      mvnerf_stream_t stream) {
     if (!z || !rgbs || !rgb || !depth) return fail(MVNERF_E_ARG, "mvnerf_composite: null pointer");

@@ -1,0 +1,540 @@
+// fp32-grade field kernel on the bf16 matrix pipe ("split3"): same math, inputs and outputs as field_eval.hip.
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate on gfx950.  Every fp32 operand is therefore cut into three
+// bf16 pieces, x = x1 + x2 + x3 (8 significand bits each, 24 together; the cut is exact: each remainder is formed by an
+// exact fp32 subtraction), and a product a.b is issued as the six bf16 MFMAs of order >= 2^-16,
+//       a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1),
+// accumulated in the fp32 accumulator (bf16 x bf16 products are exact in fp32).  The dropped terms a2 b3, a3 b2, a3 b3
+// are <= 2^-24 relative - the size of one fp32 rounding.  Measured on one 32x32xK=128 block against float64
+// (scripts/x6_probe.hip, profiles/r02_x6_probe.log): max error 6.4e-7 against 1.0e-6 for the fp32 MFMA chain - the
+// result is as close to the exact product as the fp32 MFMA's - at 6/16 of its matrix-pipe time.
+//
+// Machine mapping (as field_eval_bf16.hip): one 512-thread workgroup per CU, persistent over groups of 8 tiles of 32
+// samples; activations stay in the fp32 accumulators; the weights (split once by pack_net_split_kernel, 1.4 MiB per MLP)
+// travel through a ring of LDS slots by LDS-DMA, one k-step of 16 input rows x 4 output blocks x 3 pieces = 12 KiB per
+// slot; per k-step a wave cuts its 8 B values (relu first where the layer has one) with 5 vector instructions per value
+// (and / sub / and / sub + byte permutes, in the shadow of the other wave's MFMAs) and issues 24 MFMAs.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+
+#include "mvnerf_kernels.h"
+#include "mvnerf_math.h"
+#include "mvnerf_mfma.h"
+
+namespace mvnerf {
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+// ---- split weight stream: 1 KiB chunks [lane][8 bf16]; chunk index = 12 * kstep + 3 * nb + piece ------------------
+//   layer 0 : k-steps 0..3  = PE(cam xyz) (lower half-wave sin rows, upper cos rows) + rgb rows
+//             k-steps 4..19 = the 256 feature rows, channel 16 (ks - 4) + 8 h + jj            (direct gather only)
+//   hidden l: k-steps 20 + 8 l + (2 kb + s): input feature 32 kb + 16 s + 8 (jj >> 2) + 4 h + (jj & 3)
+//             (= accumulator registers 8 s .. 8 s + 7 of block kb fed as B operand)
+//   read-out: 8 k-steps (2 kb + s), ONE output block (rows >= 4 zero): 3 chunks per k-step, 24 chunks = 2 slots
+constexpr int kSegChunks = 12;                         // chunks per ring slot
+constexpr int kSpL0Steps = 20, kSpHiddenSteps = 96;
+constexpr int kSpReadoutChunk = (kSpL0Steps + kSpHiddenSteps) * kSegChunks;     // 1392
+constexpr int kSpChunks = kSpReadoutChunk + 24;                                 // 1416 chunks = 1.38 MiB
+constexpr int kChunkElems = 512;
+
+__global__ void pack_net_split_kernel(const float* __restrict__ src, __bf16* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kSpChunks * kChunkElems) return;
+    const int chunk = idx / kChunkElems, lane = (idx % kChunkElems) / 8, jj = idx % 8;
+    const int i = lane & 31, h = lane >> 5;
+    float val = 0.0f;
+    int piece;
+    if (chunk < kSpReadoutChunk) {
+        const int ks = chunk / kSegChunks, nb = (chunk % kSegChunks) / 3;
+        piece = chunk % 3;
+        if (ks < kSpL0Steps) {
+            int row = -1;
+            if (ks < 4) {
+                const int m = 8 * ks + jj;
+                if (m < 30) row = (m / 10) * 20 + 2 * (m % 10) + h;
+                else if (m == 30) row = 120 + h;
+                else row = h ? -1 : 122;
+            } else {
+                row = 123 + 16 * (ks - 4) + 8 * h + jj;
+            }
+            if (row >= 0) val = src[kKerasW0 + row * kHidden + 32 * nb + i];
+        } else {
+            const int q = ks - kSpL0Steps, layer = q / 8, kbs = q % 8;
+            const int f = 32 * (kbs / 2) + 16 * (kbs % 2) + 8 * (jj >> 2) + 4 * h + (jj & 3);
+            const int wsrc = kKerasBlocks + (layer / 2) * kKerasBlockStride + (layer % 2) * (kHidden * kHidden + kHidden);
+            val = src[wsrc + f * kHidden + 32 * nb + i];
+        }
+    } else {
+        const int q = chunk - kSpReadoutChunk, kbs = q / 3;
+        piece = q % 3;
+        const int f = 32 * (kbs / 2) + 16 * (kbs % 2) + 8 * (jj >> 2) + 4 * h + (jj & 3);
+        if (i < 4) val = src[kKerasWr + f * 4 + i];
+    }
+    // round-to-nearest pieces; every remainder is exact in fp32
+    const __bf16 p1 = (__bf16)val;
+    const float r1 = val - (float)p1;
+    const __bf16 p2 = (__bf16)r1;
+    const float r2 = r1 - (float)p2;
+    const __bf16 p3 = (__bf16)r2;
+    dst[idx] = piece == 0 ? p1 : (piece == 1 ? p2 : p3);
+}
+
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// Truncation cut of 8 fp32 values into 3 x 8 bf16: piece = the upper 16 bits (v_perm_b32 packs two of them), remainder =
+// x - piece (exact).  The third piece drops what is left below 24 bits (<= 2^-24 |x|).
+__device__ __forceinline__ void split3(const float (&x)[8], u32x4& p1, u32x4& p2, u32x4& p3) {
+    float r1[8], r2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const unsigned u = __builtin_bit_cast(unsigned, x[q]);
+        r1[q] = x[q] - __builtin_bit_cast(float, u & 0xffff0000u);
+        const unsigned u1 = __builtin_bit_cast(unsigned, r1[q]);
+        r2[q] = r1[q] - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        p1[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x[2 * q + 1]), __builtin_bit_cast(unsigned, x[2 * q]), 0x07060302u);
+        p2[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, r1[2 * q + 1]), __builtin_bit_cast(unsigned, r1[2 * q]), 0x07060302u);
+        p3[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, r2[2 * q + 1]), __builtin_bit_cast(unsigned, r2[2 * q]), 0x07060302u);
+    }
+}
+
+// ---- the slot ring (one k-step per slot) ---------------------------------------------------------------------------
+constexpr int kWgWaves = 8;
+constexpr int kRing = 5, kAhead = 3, kSlotF4 = kSegChunks * 64;      // float4 per slot (12 KiB)
+constexpr int kHiddenUnits = 48;                                     // k-steps of 3 ResNet blocks (6 Dense layers x 8)
+
+struct Ring {
+    const f32x4* w;
+    f32x4* base;        // LDS
+    int c;              // ring slot of the current k-step
+    int p, P, V;
+    int l0_units;       // layer-0 k-steps per view: 4 (texel table) or 20
+    int tid, wave;
+};
+
+__device__ __forceinline__ int ring_start_chunk(int p, int V, int l0_units) {
+    const int per_view = l0_units + kHiddenUnits;
+    if (p < per_view * V) {
+        const int q = p % per_view;
+        return (q < l0_units ? q : kSpL0Steps + (q - l0_units)) * kSegChunks;
+    }
+    const int q = p - per_view * V;
+    return q < kHiddenUnits ? (kSpL0Steps + kHiddenUnits + q) * kSegChunks : kSpReadoutChunk + (q - kHiddenUnits) * kSegChunks;
+}
+
+// LDS-DMA of position p + ahead into slot (c + ahead) % kRing: 12 chunks, one per wave-instruction - waves 0..3 issue two
+__device__ __forceinline__ void ring_issue(const Ring& r, int ahead) {
+    int pp = r.p + ahead;
+    if (pp >= r.P) pp -= r.P;
+    const f32x4* src = r.w + (long)ring_start_chunk(pp, r.V, r.l0_units) * 64 + r.tid;
+    f32x4* dst = r.base + ((r.c + ahead) % kRing) * kSlotF4 + 64 * r.wave;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    if (r.wave < 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * kWgWaves),
+                                         (__attribute__((address_space(3))) void*)(dst + 64 * kWgWaves), 16, 0, 0);
+}
+
+__device__ __forceinline__ const f32x4* ring_cur(const Ring& r) { return r.base + r.c * kSlotF4; }
+
+// end of a k-step: the next slot's DMA (issued kAhead - 1 k-steps ago) must have landed for every wave.  kDrain = false
+// leaves the two younger slots (4 or 2 DMA instructions of this wave) in flight; k-steps that also issue ordinary loads
+// or stores drain everything (vmcnt is in order).
+template <bool kDrain>
+__device__ __forceinline__ void ring_next(Ring& r) {
+    if (kDrain) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (r.wave < 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    r.c = r.c + 1 == kRing ? 0 : r.c + 1;
+    r.p = r.p + 1 == r.P ? 0 : r.p + 1;
+    ring_issue(r, kAhead);          // slot (c + 3) % 5 was last read two k-steps ago; everyone is past that barrier
+}
+
+// one k-step: acc[nb] += A(nb)^T b for the 4 output blocks, 6 MFMAs each (smallest terms first)
+__device__ __forceinline__ void kstep_mfma(const Ring& ring, int lane, const float (&b8)[8], f32x16 (&acc)[4]) {
+    const f32x4* wb = ring_cur(ring) + lane;
+    u32x4 a[3], b1, b2, b3;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a[q] = __builtin_bit_cast(u32x4, wb[q * 64]);
+    split3(b8, b1, b2, b3);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        u32x4 an[3];
+        if (nb < 3) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) an[q] = __builtin_bit_cast(u32x4, wb[((nb + 1) * 3 + q) * 64]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[nb] = mfma16(a[2], b1, acc[nb]);
+        acc[nb] = mfma16(a[1], b2, acc[nb]);
+        acc[nb] = mfma16(a[0], b3, acc[nb]);
+        acc[nb] = mfma16(a[1], b1, acc[nb]);
+        acc[nb] = mfma16(a[0], b2, acc[nb]);
+        acc[nb] = mfma16(a[0], b1, acc[nb]);
+        if (nb < 3) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[q] = an[q];
+        }
+    }
+}
+
+// acc += W^T relu(in) for one hidden layer: 8 k-steps (input block kb = g / 2, registers 8 (g & 1) .. + 7)
+__device__ __forceinline__ void dense128_split(Ring& ring, int lane, const f32x16 (&in)[4], f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        float b8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {          // relu on the bit pattern: one v_max_i32
+            const int bits = __builtin_bit_cast(int, in[g >> 1][8 * (g & 1) + q]);
+            b8[q] = __builtin_bit_cast(float, bits > 0 ? bits : 0);
+        }
+        kstep_mfma(ring, lane, b8, acc);
+        ring_next<false>(ring);
+    }
+}
+
+template <bool kAdd>
+__device__ __forceinline__ void bias_acc(const float* __restrict__ bperm, int h, f32x16 (&acc)[4]) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(bperm + h * 64);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = p[nb * 4 + q];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (kAdd) {
+                    // scalar adds on purpose (v_pk_add_f32 beside MFMAs costs the partner wave's matrix pipe: MI355X_MICROARCH.md)
+                    float r = acc[nb][4 * q + c];
+                    asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(r), "v"(v[c]));
+                    acc[nb][4 * q + c] = r;
+                } else {
+                    acc[nb][4 * q + c] = v[c];
+                }
+            }
+        }
+}
+
+constexpr int kStageRowBytes = 256;      // per staged sample row: 64 fp32 channels
+
+// kProj: layer 0's feature rows come from the fp32 texel table (project_texels_kernel, field_eval.hip).
+template <bool kMultiView, bool kProj>
+__global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(FieldParams p, const f32x4* __restrict__ wsplit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sp[];
+    constexpr int kRingBytes = kRing * kSlotF4 * 16;                        // 60 KiB
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* stage = smem_sp + kRingBytes + wave * (32 * kStageRowBytes);   // 8 KiB per wave
+    // all biases (accumulator order) and the read-out bias live in LDS for the whole kernel (a global load in the middle of
+    // a k-step would make the in-order vmcnt wait drain the weight prefetch)
+    float* net = reinterpret_cast<float*>(smem_sp + kRingBytes + kWgWaves * 32 * kStageRowBytes) - kPackB0;
+    for (int i = tid; i < kPackBr + 8 - kPackB0; i += 64 * kWgWaves) net[kPackB0 + i] = p.net[kPackB0 + i];
+
+    Ring ring;
+    ring.w = wsplit;
+    ring.base = reinterpret_cast<f32x4*>(smem_sp);
+    ring.c = 0;
+    ring.p = 0;
+    ring.V = p.V;
+    ring.l0_units = kProj ? 4 : kSpL0Steps;
+    ring.P = (ring.l0_units + kHiddenUnits) * p.V + kHiddenUnits + 2;
+    ring.tid = tid;
+    ring.wave = wave;
+    ring_issue(ring, 0);
+    ring_issue(ring, 1);
+    ring_issue(ring, 2);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    ring_issue(ring, kAhead);
+
+    const long n_groups = (p.n_tiles + kWgWaves - 1) / kWgWaves;
+    for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        long tile = grp * kWgWaves + wave;
+        const bool tile_ok = tile < p.n_tiles;
+        if (!tile_ok) tile = p.n_tiles - 1;                               // idle waves shadow the last tile, no stores
+        long g = tile * 32 + j;
+        const bool valid = tile_ok && g < p.total;
+        if (g >= p.total) g = p.total - 1;
+        const int ray = (int)(g / p.S);
+        const int sidx = (int)(g - (long)ray * p.S);
+        const int b = ray / p.R;
+        const float ox = p.rays_o[3 * ray + 0], oy = p.rays_o[3 * ray + 1], oz = p.rays_o[3 * ray + 2];
+        const float dx = p.rays_d[3 * ray + 0], dy = p.rays_d[3 * ray + 1], dz = p.rays_d[3 * ray + 2];
+        const float zz = p.z[g];
+        const float wx = ox + zz * dx, wy = oy + zz * dy, wz = oz + zz * dz;
+
+        f32x16 x[4], hid[4];
+        f32x16 xsum[kMultiView ? 4 : 1];
+
+        // one sample row (128 floats) from the accumulators: lane (j,h) holds features 32nb + 8q + 4h + {0..3}
+        auto store_row = [&](float* row128) {
+            float* e = row128 + 4 * h;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v4 = {x[nb][4 * q], x[nb][4 * q + 1], x[nb][4 * q + 2], x[nb][4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(e + 32 * nb + 8 * q) = v4;
+                }
+        };
+
+        for (int v = 0; v < p.V; ++v) {
+            const int bv = b * p.V + v;
+            const float* E = p.einv + 16 * bv;
+            float cam[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cam[r] = row_dot4(E, r, wx, wy, wz, 1.0f);
+            float pxl, pyl;
+            pixel_from_cam(p.k4 + 16 * bv, cam, &pxl, &pyl);
+            const Taps tp = bilinear_taps(pxl, pyl, p.H, p.W);
+            const int tl = (bv * p.H + tp.y0) * p.W + tp.x0;
+            const long vrow = ((long)bv * p.R + (ray - b * p.R)) * p.S + sidx;
+            if (valid && h == 0) {
+                if (p.tap_idx) {
+                    int4 t4 = make_int4(tl, tl + 1, tl + p.W, tl + p.W + 1);
+                    *reinterpret_cast<int4*>(p.tap_idx + 4 * vrow) = t4;
+                }
+                if (p.pix) {
+                    p.pix[2 * vrow + 0] = pxl;
+                    p.pix[2 * vrow + 1] = pyl;
+                }
+            }
+
+            // ---- 4 k-steps: PE(cam xyz) + rgb rows; accumulator seed = b0 + W0_dir^T PE(cam dir) (dir_bias_kernel) ----
+            bias_acc<false>(p.dir_bias + 128 * ((long)bv * p.R + (ray - b * p.R)), h, x);
+            float pe[32];
+            {
+                const float* img = p.images + 3 * (long)tl;
+                float rgbv[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float a = img[c] * 2.0f - 1.0f, bq = img[3 + c] * 2.0f - 1.0f;
+                    const float cq = img[3 * p.W + c] * 2.0f - 1.0f, dq = img[3 * p.W + 3 + c] * 2.0f - 1.0f;
+                    rgbv[c] = bilerp(a, bq, cq, dq, tp.ax, tp.ay);
+                }
+                pe[30] = h ? rgbv[1] : rgbv[0];
+                pe[31] = h ? 0.0f : rgbv[2];
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float a0 = cam[d] * 3.14159274101257324f;
+                float sk = 0.0f, ck = 0.0f;
+#pragma unroll
+                for (int k = 0; k < kNFreq; ++k) {
+                    if (k == 0 || k == 5) {                 // accurate seeds, double-angle steps in between (field_eval.hip)
+                        sincos_f32(a0 * (float)(1 << k), &sk, &ck);
+                    } else {
+                        const float s2 = sk + sk;
+                        const float cn = fmaf(-s2, sk, 1.0f);
+                        sk = s2 * ck;
+                        ck = cn;
+                    }
+                    pe[d * 10 + k] = h ? ck : sk;
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                float b8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) b8[q] = pe[8 * ks + q];
+                kstep_mfma(ring, lane, b8, x);
+                ring_next<true>(ring);
+            }
+
+            // ---- layer 0's 256 feature rows: 4 passes of 64 channels through the wave-private fp32 stage ----
+            // 16 lanes per sample row (16 B each), 4 rows per load instruction, 4 taps, batches of 4 instructions per tap.
+            // kProj: 2 passes over the 128-float table rows [h][nb][16] (pass P = floats h*64 + P*32 + {0..31}), lerped
+            // rows ADD into the accumulators; direct: pass = 64 raw channels, lerped rows are the B operands of 4 k-steps.
+            const int l16 = lane & 15, sub = lane >> 4;
+#pragma unroll
+            for (int P = 0; P < (kProj ? 2 : 4); ++P) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const f32x4* tbase = kProj ? reinterpret_cast<const f32x4*>(p.texel_table) + (l16 >> 3) * 16 + (l16 & 7) + P * 8
+                                           : reinterpret_cast<const f32x4*>(p.features) + P * 16 + l16;
+                const long row_f4 = kProj ? 32 : 64;                       // float4 per texel row
+#pragma unroll 1
+                for (int it0 = 0; it0 < 8; it0 += 4) {
+                    f32x4 tv[4][4];
+                    float axs[4], ays[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int src = 4 * (it0 + u) + sub;
+                        const int tls = __shfl(tl, src);
+                        axs[u] = __shfl(tp.ax, src);
+                        ays[u] = __shfl(tp.ay, src);
+                        const f32x4* f = tbase + (long)tls * row_f4;
+                        tv[u][0] = f[0];
+                        tv[u][1] = f[row_f4];
+                        tv[u][2] = f[(long)p.W * row_f4];
+                        tv[u][3] = f[(long)p.W * row_f4 + row_f4];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int src = 4 * (it0 + u) + sub;
+                        f32x4 o;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float top = fmaf(axs[u], tv[u][1][c] - tv[u][0][c], tv[u][0][c]);
+                            const float bot = fmaf(axs[u], tv[u][3][c] - tv[u][2][c], tv[u][2][c]);
+                            o[c] = fmaf(ays[u], bot - top, top);
+                        }
+                        *reinterpret_cast<f32x4*>(stage + src * kStageRowBytes + ((l16 ^ (src & 15)) << 4)) = o;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (kProj) {
+#pragma unroll
+                    for (int nbl = 0; nbl < 2; ++nbl)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 t4 = *reinterpret_cast<const f32x4*>(stage + j * kStageRowBytes + (((8 * h + 4 * nbl + q) ^ (j & 15)) << 4));
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) x[2 * P + nbl][4 * q + c] += t4[c];
+                        }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {                           // channels 64 P + 16 s + 8 h + {0..7}
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + j * kStageRowBytes + (((4 * s + 2 * h) ^ (j & 15)) << 4));
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + j * kStageRowBytes + (((4 * s + 2 * h + 1) ^ (j & 15)) << 4));
+                        const float b8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        kstep_mfma(ring, lane, b8, x);
+                        ring_next<true>(ring);
+                    }
+                }
+            }
+
+            const long vslot = (long)p.B * p.V * p.R * p.S * 128;
+            if (p.acts_view && valid) store_row(p.acts_view + 128 * vrow);
+            // ---- 48 k-steps: the three per-view ResNet blocks ----
+#pragma unroll 1
+            for (int bi = 0; bi < 3; ++bi) {
+                const float* bias1 = net + kPackBHidden + 256 * bi;
+                bias_acc<false>(bias1, h, hid);
+                dense128_split(ring, lane, x, hid);
+                bias_acc<true>(bias1 + 128, h, x);
+                dense128_split(ring, lane, hid, x);
+                if (p.acts_view && valid) store_row(p.acts_view + (bi + 1) * vslot + 128 * vrow);
+            }
+            if (kMultiView) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) xsum[nb] = (v == 0) ? x[nb] : xsum[nb] + x[nb];
+            }
+        }
+        if (kMultiView) {
+            const float nv = (float)p.V;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) x[nb] = xsum[nb] / nv;
+        }
+
+        if (p.acts_fused && valid) store_row(p.acts_fused + 128 * g);       // complete_output: the view mean
+        // ---- 48 k-steps: fusion blocks ----
+#pragma unroll 1
+        for (int bi = 3; bi < 6; ++bi) {
+            const float* bias1 = net + kPackBHidden + 256 * bi;
+            bias_acc<false>(bias1, h, hid);
+            dense128_split(ring, lane, x, hid);
+            bias_acc<true>(bias1 + 128, h, x);
+            dense128_split(ring, lane, hid, x);
+            if (p.acts_fused && valid) store_row(p.acts_fused + (long)(bi - 2) * p.total * 128 + 128 * g);
+        }
+        if (p.embedding && valid) store_row(p.embedding + 128 * g);
+
+        // ---- 2 slots: read-out, 8 k-steps x 3 pieces of ONE output block (rows >= 4 zero) ----
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = (r < 4) ? net[kPackBr + r] : 0.0f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const f32x4* wb = ring_cur(ring) + lane;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int gq = 4 * half + s4;                               // k-step (kb = gq / 2, s = gq & 1)
+                float b8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int bits = __builtin_bit_cast(int, x[gq >> 1][8 * (gq & 1) + q]);
+                    b8[q] = __builtin_bit_cast(float, bits > 0 ? bits : 0);
+                }
+                u32x4 a[3], b1, b2, b3;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a[q] = __builtin_bit_cast(u32x4, wb[(3 * s4 + q) * 64]);
+                split3(b8, b1, b2, b3);
+                o = mfma16(a[2], b1, o);
+                o = mfma16(a[1], b2, o);
+                o = mfma16(a[0], b3, o);
+                o = mfma16(a[1], b1, o);
+                o = mfma16(a[0], b2, o);
+                o = mfma16(a[0], b1, o);
+            }
+            if (half == 1 && valid && h == 0) {
+                f32x4 out;
+                out[0] = sigmoid_f32(o[0]);
+                out[1] = sigmoid_f32(o[1]);
+                out[2] = sigmoid_f32(o[2]);
+                out[3] = softplus_f32(o[3]);
+                *reinterpret_cast<f32x4*>(p.rgbs + 4 * g) = out;
+            }
+            ring_next<true>(ring);                                          // stores above: drain
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // DMA still in flight must land before the LDS is released
+}
+
+}  // namespace
+
+hipError_t launch_pack_net_split(const float* net_keras, void* packed_split, hipStream_t st) {
+    const int n = kSpChunks * kChunkElems;
+    hipLaunchKernelGGL(pack_net_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, net_keras, static_cast<__bf16*>(packed_split));
+    return hipGetLastError();
+}
+
+size_t packed_net_split_bytes() { return (size_t)kSpChunks * 1024; }
+
+hipError_t launch_field_eval_split(const FieldParams& p, const void* packed_split, hipStream_t stream) {
+    static std::mutex mtx;
+    static bool attr_done[16] = {};
+    static int cus[16] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    const int lds_bytes = kRing * kSlotF4 * 16 + kWgWaves * 32 * kStageRowBytes + (kPackBr + 8 - kPackB0) * 4;
+    {
+        std::lock_guard<std::mutex> lock(mtx);
+        if (!attr_done[dev]) {
+            hipDeviceProp_t prop;
+            if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+            cus[dev] = prop.multiProcessorCount;
+            const void* fns[4] = {reinterpret_cast<const void*>(&field_eval_split_kernel<false, false>),
+                                  reinterpret_cast<const void*>(&field_eval_split_kernel<false, true>),
+                                  reinterpret_cast<const void*>(&field_eval_split_kernel<true, false>),
+                                  reinterpret_cast<const void*>(&field_eval_split_kernel<true, true>)};
+            for (const void* fn : fns)
+                if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess) return e;
+            attr_done[dev] = true;
+        }
+    }
+    if ((e = launch_dir_bias(p, stream)) != hipSuccess) return e;
+    const long n_groups = (p.n_tiles + kWgWaves - 1) / kWgWaves;
+    const long resident = (long)cus[dev];                                   // persistent: one workgroup per CU
+    const unsigned wgs = (unsigned)(n_groups < resident ? n_groups : resident);
+    const f32x4* w = static_cast<const f32x4*>(packed_split);
+    if (p.V > 1) {
+        if (p.texel_table) hipLaunchKernelGGL((field_eval_split_kernel<true, true>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w);
+        else hipLaunchKernelGGL((field_eval_split_kernel<true, false>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w);
+    } else {
+        if (p.texel_table) hipLaunchKernelGGL((field_eval_split_kernel<false, true>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w);
+        else hipLaunchKernelGGL((field_eval_split_kernel<false, false>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mvnerf

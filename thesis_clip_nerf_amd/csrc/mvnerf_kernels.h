@@ -49,6 +49,9 @@ hipError_t launch_pack_net_bf16(const float* net_keras, void* packed16, hipStrea
 hipError_t launch_project_texels_bf16(const float* features, const void* packed16, const void* packed16b, long n_texels, float* table,
                                       float* table1, hipStream_t stream);
 hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hipStream_t stream);
+size_t packed_net_split_bytes();
+hipError_t launch_pack_net_split(const float* net_keras, void* packed_split, hipStream_t st);
+hipError_t launch_field_eval_split(const FieldParams& p, const void* packed_split, hipStream_t stream);
 
 hipError_t launch_get_rays(const double* m9, const double* origin3, const float* u, const float* v, int n_rays,
                            int width, int normalize, float* rays_o, float* rays_d, double* rays_d64,

@@ -619,6 +619,81 @@ def render_fwd_bf16(rays_o, rays_d, images, features, intrinsics, extrinsics_inv
     return rgb, depth, fine_rgb, fine_depth
 
 
+# ---- fp32-grade field pass on the bf16 matrix pipe (three-piece operand split, csrc/field_eval_split.hip) ------------------
+def pack_net_split(net_keras):
+    """Keras-order fp32 MLP -> three-piece bf16 operand stream (uint8 tensor of mvnerf_packed_net_split_bytes())."""
+    _chk(net_keras, 'net_keras', shape=(NET_PARAMS,))
+    out = torch.empty(int(_lib.lib().mvnerf_packed_net_split_bytes()), dtype=torch.uint8, device=net_keras.device)
+    with torch.cuda.device(net_keras.device):
+        _lib.check(_lib.lib().mvnerf_pack_net_split(_p(net_keras), _p(out), _stream(net_keras)), 'pack_net_split')
+    return out
+
+
+def field_eval_split(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, packed_split, return_taps=False,
+                     return_pix=False, return_embedding=False, complete_output=False, texel_table=None):
+    """mvnerf_field_eval_split: field_eval (same outputs, same fp32 bar) with the Dense layers as split-bf16 MFMA products.
+    texel_table: project_texels(features, packed_net) of the same net (fp32)."""
+    _chk(rays_o, 'rays_o', shape=(None, None, 3))
+    b, r, _ = rays_o.shape
+    _chk(rays_d, 'rays_d', shape=(b, r, 3))
+    _chk(z, 'z', shape=(b, r, None))
+    s = z.shape[2]
+    _chk(images, 'images', shape=(b, None, None, None, 3))
+    _, v, h, w, _ = images.shape
+    _chk(features, 'features', shape=(b, v, h, w, 256))
+    _chk(intrinsics, 'intrinsics', shape=(b, v, 4, 4))
+    _chk(extrinsics_inv, 'extrinsics_inv', shape=(b, v, 4, 4))
+    _chk(packed_net, 'packed_net', shape=(packed_net_floats(),))
+    _chk(packed_split, 'packed_split', dtype=torch.uint8, shape=(int(_lib.lib().mvnerf_packed_net_split_bytes()),))
+    dev = rays_o.device
+    rgbs = torch.empty((b, r, s, 4), dtype=torch.float32, device=dev)
+    taps = torch.empty((b, v, r, s, 4), dtype=torch.int32, device=dev) if return_taps else None
+    pix = torch.empty((b, v, r, s, 2), dtype=torch.float32, device=dev) if return_pix else None
+    emb = torch.empty((b, r, s, 128), dtype=torch.float32, device=dev) if return_embedding else None
+    acts_v = torch.empty((4, b * v, r, s, 128), dtype=torch.float32, device=dev) if complete_output else None
+    acts_f = torch.empty((4, b, r, s, 128), dtype=torch.float32, device=dev) if complete_output else None
+    if texel_table is not None:
+        _chk(texel_table, 'texel_table', shape=(b, v, h, w, 128))
+    ws = torch.empty(int(_lib.lib().mvnerf_field_workspace_bytes(b, v, r)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().mvnerf_field_eval_split(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(texel_table),
+                                                _p(intrinsics), _p(extrinsics_inv), _p(packed_net), _p(packed_split), b, v, r, s, h, w,
+                                                _p(rgbs), _p(taps), _p(pix), _p(emb), _p(acts_v), _p(acts_f), _p(ws), _stream(rays_o))
+    _lib.check(rc, 'field_eval_split')
+    out = (rgbs,)
+    if return_taps:
+        out += (taps,)
+    if return_pix:
+        out += (pix,)
+    if return_embedding:
+        out += (emb,)
+    if complete_output:
+        out += (list(acts_v.unbind(0)) + list(acts_f.unbind(0)),)
+    return out if len(out) > 1 else rgbs
+
+
+def render_fwd_split(rays_o, rays_d, images, features, intrinsics, extrinsics_inv, packed_coarse, packed_fine, split_coarse,
+                     split_fine, u_coarse, u_fine, near, far, q7_mode=Q7_ZERO, texel_tables='auto'):
+    """`_call` (model_v0.py:113-184) with both field passes on the split-bf16 kernel (fp32-grade products, 1e-4 bar).
+    texel_tables: 'auto' (build the two fp32 tables when texel_table_pays), None, or a (2,B,V,H,W,128) tensor to fill."""
+    geo = (images, features, intrinsics, extrinsics_inv)
+    tab_c = tab_f = None
+    if isinstance(texel_tables, str):
+        b, r, s = u_coarse.shape
+        h, w_ = images.shape[2:4]
+        texel_tables = (torch.empty((2,) + tuple(features.shape[:4]) + (128,), dtype=torch.float32, device=features.device)
+                        if texel_table_pays(r, s, h, w_) else None)
+    if texel_tables is not None:
+        tab_c, tab_f = project_texels2(features, packed_coarse, packed_fine, out=texel_tables).unbind(0)
+    z = stratified_depths(u_coarse, near, far)
+    rgbs_c = field_eval_split(rays_o, rays_d, z, *geo, packed_coarse, split_coarse, texel_table=tab_c)
+    rgb, depth, w = composite(z, rgbs_c)
+    z_all = resample(z, w, u_fine, q7_mode)
+    rgbs_f = field_eval_split(rays_o, rays_d, z_all, *geo, packed_fine, split_fine, texel_table=tab_f)
+    fine_rgb, fine_depth, _ = composite(z_all, rgbs_f, return_weights=False)
+    return rgb, depth, fine_rgb, fine_depth
+
+
 # ---- the trunk as a differentiable field on query points (SURVEY.md 8f-1; lmvnerf/model_v4.py:208-265) -------------
 def _query_shapes(points, dirs, images, features, intrinsics, extrinsics_inv):
     _chk(points, 'points', shape=(None, None, 3))
