@@ -93,7 +93,8 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(const u32x4* __restrict_
         {                                                                                           \
             float x[8];                                                                             \
             _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                         \
-                const int bits = __builtin_bit_cast(int, in[(ks) >> 1][8 * ((ks) & 1) + q]);        \
+                const float v_ = in[(ks) >> 1][8 * ((ks) & 1) + q];                                 \
+                const int bits = __builtin_bit_cast(int, v_);                                       \
                 x[q] = __builtin_bit_cast(float, bits > 0 ? bits : 0);                              \
             }                                                                                       \
             u32x4 b1, b2, b3;                                                                       \

@@ -148,8 +148,12 @@ __device__ __forceinline__ const f32x4* ring_cur(const Ring& r) { return r.base 
 // end of a k-step: the next slot's DMA (issued kAhead - 1 k-steps ago) must have landed for every wave.  kDrain = false
 // leaves the two younger slots (4 or 2 DMA instructions of this wave) in flight; k-steps that also issue ordinary loads
 // or stores drain everything (vmcnt is in order).
-template <bool kDrain>
+#ifndef MVS_DRAIN
+#define MVS_DRAIN 0        // debugging: every k-step drains all vector-memory operations
+#endif
+template <bool kDrainIn>
 __device__ __forceinline__ void ring_next(Ring& r) {
+    constexpr bool kDrain = kDrainIn || MVS_DRAIN;
     if (kDrain) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     else if (r.wave < 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
@@ -193,7 +197,8 @@ __device__ __forceinline__ void dense128_split(Ring& ring, int lane, const f32x1
         float b8[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {          // relu on the bit pattern: one v_max_i32
-            const int bits = __builtin_bit_cast(int, in[g >> 1][8 * (g & 1) + q]);
+            const float v = in[g >> 1][8 * (g & 1) + q];       // (__builtin_bit_cast straight from a vector element reads element 0)
+            const int bits = __builtin_bit_cast(int, v);
             b8[q] = __builtin_bit_cast(float, bits > 0 ? bits : 0);
         }
         kstep_mfma(ring, lane, b8, acc);
@@ -460,7 +465,8 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
                 float b8[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const int bits = __builtin_bit_cast(int, x[gq >> 1][8 * (gq & 1) + q]);
+                    const float v = x[gq >> 1][8 * (gq & 1) + q];
+                    const int bits = __builtin_bit_cast(int, v);
                     b8[q] = __builtin_bit_cast(float, bits > 0 ? bits : 0);
                 }
                 u32x4 a[3], b1, b2, b3;
