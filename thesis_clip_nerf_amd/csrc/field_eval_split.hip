@@ -28,6 +28,7 @@ namespace {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 // ---- split weight stream: 1 KiB chunks [lane][8 bf16]; chunk index = 12 * kstep + 3 * nb + piece ------------------
 //   layer 0 : k-steps 0..3  = PE(cam xyz) (lower half-wave sin rows, upper cos rows) + rgb rows
@@ -106,10 +107,46 @@ __device__ __forceinline__ void split3(const float (&x)[8], u32x4& p1, u32x4& p2
     }
 }
 
+// timing-only ablations (wrong results), scripts/ab_split.sh
+#ifndef MVS_ABL_BARRIER
+#define MVS_ABL_BARRIER 0  // no workgroup barrier at k-step ends
+#endif
+#ifndef MVS_ABL_DMA
+#define MVS_ABL_DMA 0      // every weight DMA re-reads the first slot's data
+#endif
+#ifndef MVS_ABL_SPLIT
+#define MVS_ABL_SPLIT 0    // no relu / cut of the B operands
+#endif
+#ifndef MVS_ABL_AREAD
+#define MVS_ABL_AREAD 0    // A operands not re-read from LDS
+#endif
+#ifndef MVS_ABL_GATHER
+#define MVS_ABL_GATHER 0   // no table / feature gather
+#endif
+#ifndef MVS_ABL_BIAS
+#define MVS_ABL_BIAS 0     // no bias loads / adds
+#endif
+#ifndef MVS_ABL_NODMA
+#define MVS_ABL_NODMA 0    // no weight DMA after the prologue
+#endif
+#ifndef MVS_DMA_AT
+#define MVS_DMA_AT 1       // where a k-step issues its weight DMA: after output block MVS_DMA_AT - 1 (1..4)
+#endif
+#ifndef MVS_STAGE_LATE
+#define MVS_STAGE_LATE 1   // 1: a k-step stores (after its first output block) what the PREVIOUS k-step loaded, then loads position p + 3:
+#endif                     //    the loads have a whole k-step to land before anything waits for them; 0: load p + 2, store at the k-step's end
+#ifndef MVS_STAMP
+#define MVS_STAMP 0        // debugging: per-wave cycle totals (k-step bodies / barrier waits / whole kernel) over the `pix` output
+#endif
+#ifndef MVS_DRAIN
+#define MVS_DRAIN 0        // debugging: every k-step drains all vector-memory operations
+#endif
+
 // ---- the slot ring (one k-step per slot) ---------------------------------------------------------------------------
 constexpr int kWgWaves = 8;
-constexpr int kRing = 5, kAhead = 3, kSlotF4 = kSegChunks * 64;      // float4 per slot (12 KiB)
+constexpr int kRing = 3, kSlotF4 = kSegChunks * 64;      // float4 per slot (12 KiB)
 constexpr int kHiddenUnits = 48;                                     // k-steps of 3 ResNet blocks (6 Dense layers x 8)
+constexpr int kMaxPositions = 1024;                                  // k-steps per tile the LDS position table holds
 
 struct Ring {
     const f32x4* w;
@@ -118,6 +155,19 @@ struct Ring {
     int p, P, V;
     int l0_units;       // layer-0 k-steps per view: 4 (texel table) or 20
     int tid, wave;
+    const int* table;   // LDS: first chunk of every position of one tile
+    int start_pf;       // table entry (first chunk) of the position the next ring_fetch loads, read one k-step ahead
+    int off_a, off_b;   // this thread's 16 + 8 bytes inside a slot: wave * 1536 + lane * 16 | wave * 1536 + 1024 + lane * 8
+    f32x4 stg0;         // the fetched bytes on their way to LDS
+    f32x2 stg1;
+#if MVS_STAMP
+    unsigned long long t_last, t_body, t_wait, t_grp[4], t_mark;
+#endif
+    u32x4 a0[3];        // A operands (3 pieces) of output block 0 of the CURRENT k-step, read during the previous one
+};
+
+struct BParts {
+    u32x4 p1, p2, p3;
 };
 
 __device__ __forceinline__ int ring_start_chunk(int p, int V, int l0_units) {
@@ -130,84 +180,186 @@ __device__ __forceinline__ int ring_start_chunk(int p, int V, int l0_units) {
     return q < kHiddenUnits ? (kSpL0Steps + kHiddenUnits + q) * kSegChunks : kSpReadoutChunk + (q - kHiddenUnits) * kSegChunks;
 }
 
-// LDS-DMA of position p + ahead into slot (c + ahead) % kRing: 12 chunks, one per wave-instruction - waves 0..3 issue two
-__device__ __forceinline__ void ring_issue(const Ring& r, int ahead) {
-    int pp = r.p + ahead;
-    if (pp >= r.P) pp -= r.P;
-    const f32x4* src = r.w + (long)ring_start_chunk(pp, r.V, r.l0_units) * 64 + r.tid;
-    f32x4* dst = r.base + ((r.c + ahead) % kRing) * kSlotF4 + 64 * r.wave;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    if (r.wave < 4)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * kWgWaves),
-                                         (__attribute__((address_space(3))) void*)(dst + 64 * kWgWaves), 16, 0, 0);
+// The weight stream reaches LDS through registers: after its first output block a k-step at position p stores what the
+// previous k-step loaded (position p + 2, 12 KiB contiguous in the stream: every thread one dwordx4 + one dwordx2 = 24 B,
+// the same two instructions in every wave, no branch) into slot (c + 2) % 3 and loads position p + 3 into the same
+// registers - a whole k-step of matrix work lies between a load and the store that waits for it.  LDS-DMA (global_load_lds) looked like the natural tool and was the first version, but a CU accepts
+// only about one 1 KiB DMA instruction per ~110 cycles (in-kernel stamps; MI355X_MICROARCH.md quotes 25 GB/s per CU for
+// LDS-DMA fills) - 12 per k-step is 1300 cycles of blocked instruction issue against 1536 cycles of matrix work; the
+// vector-memory path does the same 12 KiB at 64 B/clk.
+__device__ __forceinline__ void ring_store(Ring& r) {
+    if (MVS_ABL_NODMA) return;
+    int slot = r.c + 2;
+    slot = slot >= kRing ? slot - kRing : slot;
+    char* dst = reinterpret_cast<char*>(r.base) + slot * (kSlotF4 * 16);
+    *reinterpret_cast<f32x4*>(dst + r.off_a) = r.stg0;
+    *reinterpret_cast<f32x2*>(dst + r.off_b) = r.stg1;
+}
+
+__device__ __forceinline__ void ring_fetch(Ring& r) {
+    if (MVS_ABL_NODMA) return;
+    if (MVS_STAGE_LATE) ring_store(r);                                  // position p + 2, loaded one k-step ago
+    const char* src = reinterpret_cast<const char*>(r.w) + (long)(MVS_ABL_DMA ? 0 : r.start_pf) * 1024;
+    r.stg0 = *reinterpret_cast<const f32x4*>(src + r.off_a);
+    r.stg1 = *reinterpret_cast<const f32x2*>(src + r.off_b);
+    int pp = r.p + 3 + MVS_STAGE_LATE;                                  // table entry the NEXT k-step's fetch needs
+    pp = pp >= r.P ? pp - r.P : pp;
+    r.start_pf = r.table[pp];
 }
 
 __device__ __forceinline__ const f32x4* ring_cur(const Ring& r) { return r.base + r.c * kSlotF4; }
+__device__ __forceinline__ const f32x4* ring_nxt(const Ring& r) { return r.base + (r.c + 1 == kRing ? 0 : r.c + 1) * kSlotF4; }
 
-// end of a k-step: the next slot's DMA (issued kAhead - 1 k-steps ago) must have landed for every wave.  kDrain = false
-// leaves the two younger slots (4 or 2 DMA instructions of this wave) in flight; k-steps that also issue ordinary loads
-// or stores drain everything (vmcnt is in order).
-#ifndef MVS_DRAIN
-#define MVS_DRAIN 0        // debugging: every k-step drains all vector-memory operations
-#endif
-template <bool kDrainIn>
+// End of the k-step at position p (slot c): the fetched position p + 2 goes into slot (c + 2) % 3 - the slot of position
+// p - 1, which nobody reads any more since the previous barrier - and the barrier publishes it.  A k-step reads its own slot
+// and, for the A operands of the next k-step's first output block, the next one: both were published at least one barrier
+// ago.
 __device__ __forceinline__ void ring_next(Ring& r) {
-    constexpr bool kDrain = kDrainIn || MVS_DRAIN;
-    if (kDrain) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (r.wave < 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+#if MVS_STAMP
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    r.t_body += t1 - r.t_last;
+#endif
+    if (!MVS_STAGE_LATE) ring_store(r);
+#if MVS_ABL_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+#if MVS_STAMP
+    r.t_last = __builtin_readcyclecounter();
+    r.t_wait += r.t_last - t1;
+#endif
     r.c = r.c + 1 == kRing ? 0 : r.c + 1;
     r.p = r.p + 1 == r.P ? 0 : r.p + 1;
-    ring_issue(r, kAhead);          // slot (c + 3) % 5 was last read two k-steps ago; everyone is past that barrier
 }
 
-// one k-step: acc[nb] += A(nb)^T b for the 4 output blocks, 6 MFMAs each (smallest terms first)
-__device__ __forceinline__ void kstep_mfma(const Ring& ring, int lane, const float (&b8)[8], f32x16 (&acc)[4]) {
-    const f32x4* wb = ring_cur(ring) + lane;
-    u32x4 a[3], b1, b2, b3;
+// values 2q, 2q+1 of an 8-value B operand -> dword q of the three pieces (relu first where the layer has one)
+template <bool kRelu>
+__device__ __forceinline__ void split_pair(float v0, float v1, int q, BParts& b) {
+#if MVS_ABL_SPLIT
+    b.p1[q] = __builtin_bit_cast(unsigned, v0);
+    b.p2[q] = __builtin_bit_cast(unsigned, v1);
+    b.p3[q] = __builtin_bit_cast(unsigned, v0);
+    return;
+#endif
+    if (kRelu) {               // relu on the bit pattern: one v_max_i32
+        const int i0 = __builtin_bit_cast(int, v0), i1 = __builtin_bit_cast(int, v1);
+        v0 = __builtin_bit_cast(float, i0 > 0 ? i0 : 0);
+        v1 = __builtin_bit_cast(float, i1 > 0 ? i1 : 0);
+    }
+    const float r0 = v0 - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v0) & 0xffff0000u);
+    const float r1 = v1 - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v1) & 0xffff0000u);
+    const float s0 = r0 - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r0) & 0xffff0000u);
+    const float s1 = r1 - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & 0xffff0000u);
+    b.p1[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, v1), __builtin_bit_cast(unsigned, v0), 0x07060302u);
+    b.p2[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, r1), __builtin_bit_cast(unsigned, r0), 0x07060302u);
+    b.p3[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+}
+
+template <bool kRelu>
+__device__ __forceinline__ void split8(const float (&v)[8], BParts& b) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) a[q] = __builtin_bit_cast(u32x4, wb[q * 64]);
-    split3(b8, b1, b2, b3);
+    for (int q = 0; q < 4; ++q) split_pair<kRelu>(v[2 * q], v[2 * q + 1], q, b);
+}
+
+// One k-step: acc[nb] += A(nb)^T b for the 4 output blocks, 6 MFMAs each (smallest terms first).  Software pipeline: while
+// the MFMAs of output block nb run, the A operands of the next block (of the NEXT k-step's block 0 at nb = 3) are read
+// from LDS and, with kNext, a quarter of the next k-step's B operand is cut on the vector ALU - two vector instructions per
+// MFMA gap, which the matrix pipe hides (MI355X_MICROARCH.md: <= 5 single-issue fillers per 32x32x16 MFMA).
+template <bool kRelu, bool kNext>
+__device__ __forceinline__ void kstep_mfma(Ring& ring, int lane, const BParts& b, const float (&n8)[8], BParts& bn, f32x16 (&acc)[4]) {
+    const f32x4* cur = ring_cur(ring) + lane;
+    const f32x4* nxt = ring_nxt(ring) + lane;
+    u32x4 a[3] = {ring.a0[0], ring.a0[1], ring.a0[2]};
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         u32x4 an[3];
-        if (nb < 3) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) an[q] = __builtin_bit_cast(u32x4, wb[((nb + 1) * 3 + q) * 64]);
+        for (int q = 0; q < 3; ++q) an[q] = MVS_ABL_AREAD ? a[(q + 1) % 3] : __builtin_bit_cast(u32x4, nb < 3 ? cur[((nb + 1) * 3 + q) * 64] : nxt[q * 64]);
+        if (kNext) split_pair<kRelu>(n8[2 * nb], n8[2 * nb + 1], nb, bn);
+        acc[nb] = mfma16(a[2], b.p1, acc[nb]);
+        acc[nb] = mfma16(a[1], b.p2, acc[nb]);
+        acc[nb] = mfma16(a[0], b.p3, acc[nb]);
+        acc[nb] = mfma16(a[1], b.p1, acc[nb]);
+        acc[nb] = mfma16(a[0], b.p2, acc[nb]);
+        acc[nb] = mfma16(a[0], b.p1, acc[nb]);
+        // issue order inside the group: the first MFMA (its operands were requested one group ago, so the LDS wait in front
+        // of it covers nothing newer), then the three LDS reads of the next group, then MFMA / 2 VALU alternating
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        if (kNext) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (kNext) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (kNext) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
         __builtin_amdgcn_sched_barrier(0);
-        acc[nb] = mfma16(a[2], b1, acc[nb]);
-        acc[nb] = mfma16(a[1], b2, acc[nb]);
-        acc[nb] = mfma16(a[0], b3, acc[nb]);
-        acc[nb] = mfma16(a[1], b1, acc[nb]);
-        acc[nb] = mfma16(a[0], b2, acc[nb]);
-        acc[nb] = mfma16(a[0], b1, acc[nb]);
-        if (nb < 3) {
+#if MVS_STAMP
+        {
+            const unsigned long long tg = __builtin_readcyclecounter();
+            ring.t_grp[nb] += tg - (nb == 0 ? ring.t_last : ring.t_mark);
+            ring.t_mark = tg;
+        }
+#endif
+        if (nb + 1 == MVS_DMA_AT) {   // the weight loads of two k-steps ahead
+            ring_fetch(ring);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-            for (int q = 0; q < 3; ++q) a[q] = an[q];
+        for (int q = 0; q < 3; ++q) a[q] = an[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ring.a0[q] = a[q];
+    if (kNext) {
+        // pin the pieces of the next operand HERE: the k-step ends in ring_next's wave-uniform branches, and the machine sinker
+        // would otherwise move the whole cut into the next k-step's block - behind the barrier, where nothing hides it
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned u1 = bn.p1[q], u2 = bn.p2[q], u3 = bn.p3[q];
+            asm volatile("" : "+v"(u1), "+v"(u2), "+v"(u3));
+            bn.p1[q] = u1;
+            bn.p2[q] = u2;
+            bn.p3[q] = u3;
         }
     }
 }
 
-// acc += W^T relu(in) for one hidden layer: 8 k-steps (input block kb = g / 2, registers 8 (g & 1) .. + 7)
+// acc += W^T relu(in) for one hidden layer: 8 k-steps (input block kb = g / 2, registers 8 (g & 1) .. + 7).  The cut of
+// k-step 0's operand cannot overlap anything of this wave (it needs the previous layer's last MFMA); k-steps 1..7 are cut
+// during the MFMAs of their predecessors.
 __device__ __forceinline__ void dense128_split(Ring& ring, int lane, const f32x16 (&in)[4], f32x16 (&acc)[4]) {
+    BParts b, bn;
+    {
+        float v8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v8[q] = in[0][q];
+        split8<true>(v8, b);
+    }
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
-        float b8[8];
+        float n8[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {          // relu on the bit pattern: one v_max_i32
-            const float v = in[g >> 1][8 * (g & 1) + q];       // (__builtin_bit_cast straight from a vector element reads element 0)
-            const int bits = __builtin_bit_cast(int, v);
-            b8[q] = __builtin_bit_cast(float, bits > 0 ? bits : 0);
-        }
-        kstep_mfma(ring, lane, b8, acc);
-        ring_next<false>(ring);
+        for (int q = 0; q < 8; ++q) n8[q] = g < 7 ? in[(g + 1) >> 1][8 * ((g + 1) & 1) + q] : 0.0f;
+        if (g < 7) kstep_mfma<true, true>(ring, lane, b, n8, bn, acc);
+        else kstep_mfma<true, false>(ring, lane, b, n8, bn, acc);
+        b = bn;
+        ring_next(ring);
     }
 }
 
 template <bool kAdd>
 __device__ __forceinline__ void bias_acc(const float* __restrict__ bperm, int h, f32x16 (&acc)[4]) {
+#if MVS_ABL_BIAS
+    if (!kAdd) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = (float)h;
+    }
+    return;
+#endif
     const f32x4* p = reinterpret_cast<const f32x4*>(bperm + h * 64);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
@@ -234,7 +386,7 @@ constexpr int kStageRowBytes = 256;      // per staged sample row: 64 fp32 chann
 template <bool kMultiView, bool kProj>
 __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(FieldParams p, const f32x4* __restrict__ wsplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sp[];
-    constexpr int kRingBytes = kRing * kSlotF4 * 16;                        // 60 KiB
+    constexpr int kRingBytes = kRing * kSlotF4 * 16;                        // 36 KiB
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char* stage = smem_sp + kRingBytes + wave * (32 * kStageRowBytes);   // 8 KiB per wave
@@ -253,11 +405,37 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
     ring.P = (ring.l0_units + kHiddenUnits) * p.V + kHiddenUnits + 2;
     ring.tid = tid;
     ring.wave = wave;
-    ring_issue(ring, 0);
-    ring_issue(ring, 1);
-    ring_issue(ring, 2);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    ring_issue(ring, kAhead);
+    {   // chunk every position of a tile starts at
+        int* table = reinterpret_cast<int*>(smem_sp + kRingBytes + kWgWaves * 32 * kStageRowBytes + (kPackBr + 8 - kPackB0) * 4);
+        for (int i = tid; i < ring.P; i += 64 * kWgWaves) table[i] = ring_start_chunk(i, p.V, ring.l0_units);
+        ring.table = table;
+    }
+    __syncthreads();                                                        // the position table is written
+    ring.off_a = wave * 1536 + lane * 16;
+    ring.off_b = wave * 1536 + 1024 + lane * 8;
+    for (int q = 0; q < 2; ++q) {                                           // prologue: positions 0 and 1 into slots 0 and 1
+        const char* src = reinterpret_cast<const char*>(wsplit) + (long)ring.table[q] * 1024;
+        char* dst = reinterpret_cast<char*>(ring.base) + q * (kSlotF4 * 16);
+        *reinterpret_cast<f32x4*>(dst + ring.off_a) = *reinterpret_cast<const f32x4*>(src + ring.off_a);
+        *reinterpret_cast<f32x2*>(dst + ring.off_b) = *reinterpret_cast<const f32x2*>(src + ring.off_b);
+    }
+    if (MVS_STAGE_LATE) {
+        const char* src = reinterpret_cast<const char*>(wsplit) + (long)ring.table[2] * 1024;
+        ring.stg0 = *reinterpret_cast<const f32x4*>(src + ring.off_a);
+        ring.stg1 = *reinterpret_cast<const f32x2*>(src + ring.off_b);
+    }
+    ring.start_pf = ring.table[2 + MVS_STAGE_LATE];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ring.a0[q] = __builtin_bit_cast(u32x4, ring_cur(ring)[q * 64 + lane]);
+#if MVS_STAMP
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+    ring.t_last = t_begin;
+    ring.t_body = 0;
+    ring.t_wait = 0;
+    ring.t_mark = 0;
+    for (int q = 0; q < 4; ++q) ring.t_grp[q] = 0;
+#endif
 
     const long n_groups = (p.n_tiles + kWgWaves - 1) / kWgWaves;
     for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
@@ -344,13 +522,22 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
                     pe[d * 10 + k] = h ? ck : sk;
                 }
             }
+            {
+                BParts bq, bqn;
+                float v8[8];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                float b8[8];
+                for (int q = 0; q < 8; ++q) v8[q] = pe[q];
+                split8<false>(v8, bq);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) b8[q] = pe[8 * ks + q];
-                kstep_mfma(ring, lane, b8, x);
-                ring_next<true>(ring);
+                for (int ks = 0; ks < 4; ++ks) {
+                    float n8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) n8[q] = ks < 3 ? pe[8 * (ks + 1) + q] : 0.0f;
+                    if (ks < 3) kstep_mfma<false, true>(ring, lane, bq, n8, bqn, x);
+                    else kstep_mfma<false, false>(ring, lane, bq, n8, bqn, x);
+                    bq = bqn;
+                    ring_next(ring);
+                }
             }
 
             // ---- layer 0's 256 feature rows: 4 passes of 64 channels through the wave-private fp32 stage ----
@@ -365,7 +552,7 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
                                            : reinterpret_cast<const f32x4*>(p.features) + P * 16 + l16;
                 const long row_f4 = kProj ? 32 : 64;                       // float4 per texel row
 #pragma unroll 1
-                for (int it0 = 0; it0 < 8; it0 += 4) {
+                for (int it0 = 0; it0 < (MVS_ABL_GATHER ? 0 : 8); it0 += 4) {
                     f32x4 tv[4][4];
                     float axs[4], ays[4];
 #pragma unroll
@@ -410,8 +597,10 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
                         const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + j * kStageRowBytes + (((4 * s + 2 * h) ^ (j & 15)) << 4));
                         const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + j * kStageRowBytes + (((4 * s + 2 * h + 1) ^ (j & 15)) << 4));
                         const float b8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        kstep_mfma(ring, lane, b8, x);
-                        ring_next<true>(ring);
+                        BParts bq, bqn;
+                        split8<false>(b8, bq);
+                        kstep_mfma<false, false>(ring, lane, bq, b8, bqn, x);
+                        ring_next(ring);
                     }
                 }
             }
@@ -464,21 +653,18 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
                 const int gq = 4 * half + s4;                               // k-step (kb = gq / 2, s = gq & 1)
                 float b8[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float v = x[gq >> 1][8 * (gq & 1) + q];
-                    const int bits = __builtin_bit_cast(int, v);
-                    b8[q] = __builtin_bit_cast(float, bits > 0 ? bits : 0);
-                }
-                u32x4 a[3], b1, b2, b3;
+                for (int q = 0; q < 8; ++q) b8[q] = x[gq >> 1][8 * (gq & 1) + q];
+                BParts bq;
+                split8<true>(b8, bq);
+                u32x4 a[3];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) a[q] = __builtin_bit_cast(u32x4, wb[(3 * s4 + q) * 64]);
-                split3(b8, b1, b2, b3);
-                o = mfma16(a[2], b1, o);
-                o = mfma16(a[1], b2, o);
-                o = mfma16(a[0], b3, o);
-                o = mfma16(a[1], b1, o);
-                o = mfma16(a[0], b2, o);
-                o = mfma16(a[0], b1, o);
+                for (int q = 0; q < 3; ++q) a[q] = s4 == 0 ? ring.a0[q] : __builtin_bit_cast(u32x4, wb[(3 * s4 + q) * 64]);
+                o = mfma16(a[2], bq.p1, o);
+                o = mfma16(a[1], bq.p2, o);
+                o = mfma16(a[0], bq.p3, o);
+                o = mfma16(a[1], bq.p1, o);
+                o = mfma16(a[0], bq.p2, o);
+                o = mfma16(a[0], bq.p1, o);
             }
             if (half == 1 && valid && h == 0) {
                 f32x4 out;
@@ -488,10 +674,26 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
                 out[3] = softplus_f32(o[3]);
                 *reinterpret_cast<f32x4*>(p.rgbs + 4 * g) = out;
             }
-            ring_next<true>(ring);                                          // stores above: drain
+            ring_fetch(ring);
+            // the next position's first A operands (the invariant every k-step leaves behind)
+            {
+                const f32x4* nx = ring_nxt(ring) + lane;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) ring.a0[q] = __builtin_bit_cast(u32x4, nx[q * 64]);
+            }
+            ring_next(ring);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // DMA still in flight must land before the LDS is released
+#if MVS_STAMP
+    if (lane == 0 && p.pix) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.pix) + 8 * (blockIdx.x * kWgWaves + wave);
+        dbg[0] = ring.t_body;
+        dbg[1] = ring.t_wait;
+        dbg[2] = __builtin_readcyclecounter() - t_begin;
+        dbg[3] = t_begin;
+        for (int q = 0; q < 4; ++q) dbg[4 + q] = ring.t_grp[q];
+    }
+#endif
 }
 
 }  // namespace
@@ -512,7 +714,9 @@ hipError_t launch_field_eval_split(const FieldParams& p, const void* packed_spli
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-    const int lds_bytes = kRing * kSlotF4 * 16 + kWgWaves * 32 * kStageRowBytes + (kPackBr + 8 - kPackB0) * 4;
+    const int n_pos = ((p.texel_table ? 4 : kSpL0Steps) + kHiddenUnits) * p.V + kHiddenUnits + 2;
+    if (n_pos > kMaxPositions) return hipErrorInvalidValue;                  // V <= 14 (direct) / 18 (texel table)
+    const int lds_bytes = kRing * kSlotF4 * 16 + kWgWaves * 32 * kStageRowBytes + (kPackBr + 8 - kPackB0) * 4 + kMaxPositions * 4;
     {
         std::lock_guard<std::mutex> lock(mtx);
         if (!attr_done[dev]) {
