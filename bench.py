@@ -100,7 +100,7 @@ def main():
     ap.add_argument('--rays', type=int, default=0, help='random target pixels instead of every pixel of a size x size view (e.g. cfg5: 16384 rays, 480x640 sources)')
     ap.add_argument('--cpu-baseline', default='on', choices=['on', 'off'], help='N=1: time the torch-CPU restatement and check parity on all rays')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='bf16: both field passes on the bf16 MFMA kernel (configs 3/5; not the headline)')
-    ap.add_argument('--f32-gemm', default='mfma_f32', choices=['mfma_f32', 'split_bf16'],
+    ap.add_argument('--f32-gemm', default='split_bf16', choices=['mfma_f32', 'split_bf16'],
                     help='fp32 Dense layers on the fp32 MFMA, or as six bf16 MFMAs per product on exactly split operands (fp32-grade, csrc/field_eval_split.hip)')
     ap.add_argument('--texel-table', default='auto', choices=['auto', 'on', 'off'],
                     help="hoist layer 0's feature rows to a per-texel table rebuilt every step (auto: when R*S >= 2*H*W)")
@@ -188,9 +188,9 @@ def main():
 
     def step_fused(e=None):
         return ops.render_fwd(t['rays_o'], t['rays_d'], *field_args, pc, pf, t['u_coarse'], t['u_fine'], near, far,
-                              workspace=ws, texel_tables=tables)
+                              workspace=ws, texel_tables=tables, split=(pcs, pfs) if split else None)
 
-    step = step_fused if (args.fused_call and not bf16 and not split) else step_ops
+    step = step_fused if (args.fused_call and not bf16) else step_ops
     for _ in range(args.warmup):
         out = step()
     barrier()

@@ -316,6 +316,16 @@ int mvnerf_render_fwd(const float* rays_o, const float* rays_d, const float* ima
                       float* depth, float* fine_rgb, float* fine_depth, void* workspace, float* texel_tables,
                       int tables_ready, mvnerf_stream_t stream);
 
+/* mvnerf_render_fwd with both field passes on the split-bf16 kernel (mvnerf_field_eval_split): split_coarse / split_fine =
+ * mvnerf_pack_net_split of the two nets; packed_coarse / packed_fine still supply biases, the per-ray layer-0 seed and the
+ * texel tables.  Same outputs, same 1e-4 bar. */
+int mvnerf_render_fwd_split(const float* rays_o, const float* rays_d, const float* images, const float* features,
+                            const float* intrinsics, const float* extrinsics_inv, const float* packed_coarse,
+                            const float* packed_fine, const void* split_coarse, const void* split_fine, const float* u_coarse,
+                            const float* u_fine, int B, int V, int R, int S, int H, int W, double near_, double far_, int q7_mode,
+                            float* rgb, float* depth, float* fine_rgb, float* fine_depth, void* workspace, float* texel_tables,
+                            int tables_ready, mvnerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,8 @@ SIGNATURES = {
     'mvnerf_render_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'mvnerf_render_fwd': (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_double, c_double, c_int] + [c_void_p] * 6 +
                           [c_int, c_void_p]),
+    'mvnerf_render_fwd_split': (c_int, [c_void_p] * 12 + [c_int] * 6 + [c_double, c_double, c_int] + [c_void_p] * 6 +
+                                [c_int, c_void_p]),
 }
 
 _lib = None

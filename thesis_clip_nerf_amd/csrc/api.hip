@@ -624,4 +624,41 @@ int mvnerf_render_fwd(const float* rays_o, const float* rays_d, const float* ima
     return mvnerf_composite(w.z_all, w.rgbs_f, (int)n_rays, 2 * S, fine_rgb, fine_depth, nullptr, stream);
 }
 
+int mvnerf_render_fwd_split(const float* rays_o, const float* rays_d, const float* images, const float* features,
+                            const float* intrinsics, const float* extrinsics_inv, const float* packed_coarse,
+                            const float* packed_fine, const void* split_coarse, const void* split_fine, const float* u_coarse,
+                            const float* u_fine, int B, int V, int R, int S, int H, int W, double near_, double far_, int q7_mode,
+                            float* rgb, float* depth, float* fine_rgb, float* fine_depth, void* workspace, float* texel_tables,
+                            int tables_ready, mvnerf_stream_t stream) {
+    if (!u_coarse || !u_fine || !rgb || !depth || !fine_rgb || !fine_depth || !workspace || !packed_fine || !split_coarse || !split_fine)
+        return fail(MVNERF_E_ARG, "mvnerf_render_fwd_split: null pointer");
+    if (S != 64) return fail(MVNERF_E_SHAPE, "mvnerf_render_fwd_split: S=%d, only the reference's n_samples=64 is built", S);
+    if (B <= 0 || R <= 0) return fail(MVNERF_E_ARG, "mvnerf_render_fwd_split: B=%d R=%d", B, R);
+    if (!aligned16(workspace)) return fail(MVNERF_E_ALIGN, "mvnerf_render_fwd_split: workspace must be 16-byte aligned");
+    const long n_rays = (long)B * R;
+    if (n_rays * 2 * S >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_render_fwd_split: B*R*2S too large");
+    const Workspace w = carve(workspace, n_rays, V, S);
+    int rc;
+    const float *table_c = nullptr, *table_f = nullptr;
+    if (texel_tables) {                                       // [coarse net | fine net], mvnerf_texel_table_bytes each
+        float* tf = texel_tables + mvnerf_texel_table_bytes(B, V, H, W) / sizeof(float);
+        if (!tables_ready) {
+            if ((rc = mvnerf_project_texels2(features, packed_coarse, packed_fine, B, V, H, W, texel_tables, tf, stream))) return rc;
+        }
+        table_c = texel_tables;
+        table_f = tf;
+    }
+    if ((rc = mvnerf_stratified_depths(u_coarse, (int)n_rays, S, near_, far_, w.z, stream))) return rc;
+    if ((rc = mvnerf_field_eval_split(rays_o, rays_d, w.z, images, features, table_c, intrinsics, extrinsics_inv, packed_coarse, split_coarse,
+                                      B, V, R, S, H, W, w.rgbs_c, nullptr, nullptr, nullptr, nullptr, nullptr, w.dir_bias, stream)))
+        return rc;
+    if ((rc = mvnerf_composite(w.z, w.rgbs_c, (int)n_rays, S, rgb, depth, w.weights, stream))) return rc;
+    if ((rc = mvnerf_resample(w.z, w.weights, u_fine, (int)n_rays, S, q7_mode, w.z_all, nullptr, nullptr, nullptr, nullptr, stream)))
+        return rc;
+    if ((rc = mvnerf_field_eval_split(rays_o, rays_d, w.z_all, images, features, table_f, intrinsics, extrinsics_inv, packed_fine, split_fine,
+                                      B, V, R, 2 * S, H, W, w.rgbs_f, nullptr, nullptr, nullptr, nullptr, nullptr, w.dir_bias, stream)))
+        return rc;
+    return mvnerf_composite(w.z_all, w.rgbs_f, (int)n_rays, 2 * S, fine_rgb, fine_depth, nullptr, stream);
+}
+
 }  // extern "C"

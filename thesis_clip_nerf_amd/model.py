@@ -37,7 +37,7 @@ class MVVNeRFRenderer:
 
     def __init__(self, n_rays_train, n_rays_infer, n_views=2, n_samples=64, n_features=256,
                  embed_direction_vector=True, batch_size=1, near=0.7, far=1.5, original_image_size=(480, 640),
-                 device='cuda', seed=0, feature_encoder=None, q7_mode=Q7_ZERO, compute_dtype='f32'):
+                 device='cuda', seed=0, feature_encoder=None, q7_mode=Q7_ZERO, compute_dtype='f32', f32_gemm='split_bf16'):
         if n_features != 256:
             raise ValueError('n_features must be 256 (the HIP kernels are built for the reference feature width)')
         if not embed_direction_vector:
@@ -59,11 +59,15 @@ class MVVNeRFRenderer:
         if compute_dtype not in ('f32', 'bf16'):
             raise ValueError("compute_dtype must be 'f32' (reference precision) or 'bf16' (bf16 MFMA inputs, fp32 accumulate)")
         self.compute_dtype = compute_dtype       # inference only; training always runs the fp32 path
+        if f32_gemm not in ('split_bf16', 'mfma_f32'):
+            raise ValueError("f32_gemm must be 'split_bf16' (six bf16 MFMAs per product on exactly cut operands, fp32-grade) or 'mfma_f32'")
+        self.f32_gemm = f32_gemm                 # how compute_dtype='f32' inference runs its Dense layers (same results to ~1e-6)
         rng = np.random.default_rng(seed)
         self.coarse_net = torch.from_numpy(glorot_net(rng)).to(self.device)      # Keras glorot_uniform, zero bias
         self.fine_net = torch.from_numpy(glorot_net(rng)).to(self.device)
         self._packed = None
         self._packed16 = None
+        self._packed_split = None
         self._packed_bwd = None
         self._workspace = None
         self._tables = None             # (2,B,V,H,W,128) texel tables [coarse | fine] of the last scene, see _call
@@ -92,7 +96,14 @@ class MVVNeRFRenderer:
         if self._packed is None:
             self._packed = (ops.pack_net(self.coarse_net), ops.pack_net(self.fine_net))
             self._packed16 = None
+            self._packed_split = None
         return self._packed
+
+    def packed_split(self):
+        self.packed()
+        if self._packed_split is None:
+            self._packed_split = (ops.pack_net_split(self.coarse_net), ops.pack_net_split(self.fine_net))
+        return self._packed_split
 
     def packed16(self):
         self.packed()
@@ -149,7 +160,7 @@ class MVVNeRFRenderer:
             self._tables_key = scene_key
         return ops.render_fwd(rays_o, rays_d, images, features, k4, einv, pc, pf, self._dev(u_coarse), self._dev(u_fine),
                               self.near, self.far, self.q7_mode, workspace=self._workspace, texel_tables=tables,
-                              tables_ready=ready)
+                              tables_ready=ready, split=self.packed_split() if self.f32_gemm == 'split_bf16' else None)
 
     def infer(self, inputs, batched_features, **kw):
         """model_v0.py:61-63 (any ray count, not only n_rays_infer=512)."""

@@ -244,8 +244,9 @@ def render_workspace_bytes(b, v, r, s):
 
 
 def render_fwd(rays_o, rays_d, images, features, intrinsics, extrinsics_inv, packed_coarse, packed_fine, u_coarse,
-               u_fine, near, far, q7_mode=Q7_ZERO, workspace=None, out=None, texel_tables=None, tables_ready=False):
+               u_fine, near, far, q7_mode=Q7_ZERO, workspace=None, out=None, texel_tables=None, tables_ready=False, split=None):
     """mvnerf_render_fwd = MVVNeRFRenderer._call (model_v0.py:113-184) -> (rgb, depth, fine_rgb, fine_depth).
+    split: (pack_net_split(coarse), pack_net_split(fine)) -> mvnerf_render_fwd_split (fp32-grade Dense layers on the bf16 MFMA).
     texel_tables: None = gather raw features; 'auto' = allocate and build when texel_table_pays(); or a float32
     tensor (2,B,V,H,W,128) [coarse net | fine net], built by this call unless tables_ready."""
     _chk(rays_o, 'rays_o', shape=(None, None, 3))
@@ -282,11 +283,21 @@ def render_fwd(rays_o, rays_d, images, features, intrinsics, extrinsics_inv, pac
     if texel_tables is not None:
         _chk(texel_tables, 'texel_tables', shape=(2, b, v, h, w, 128))
     with torch.cuda.device(dev):
-        rc = _lib.lib().mvnerf_render_fwd(_p(rays_o), _p(rays_d), _p(images), _p(features), _p(intrinsics),
-                                          _p(extrinsics_inv), _p(packed_coarse), _p(packed_fine), _p(u_coarse),
-                                          _p(u_fine), b, v, r, s, h, w, float(near), float(far), int(q7_mode), _p(rgb),
-                                          _p(depth), _p(fine_rgb), _p(fine_depth), _p(workspace), _p(texel_tables),
-                                          int(bool(tables_ready)), _stream(rays_o))
+        if split is None:
+            rc = _lib.lib().mvnerf_render_fwd(_p(rays_o), _p(rays_d), _p(images), _p(features), _p(intrinsics),
+                                              _p(extrinsics_inv), _p(packed_coarse), _p(packed_fine), _p(u_coarse),
+                                              _p(u_fine), b, v, r, s, h, w, float(near), float(far), int(q7_mode), _p(rgb),
+                                              _p(depth), _p(fine_rgb), _p(fine_depth), _p(workspace), _p(texel_tables),
+                                              int(bool(tables_ready)), _stream(rays_o))
+        else:
+            nbytes = int(_lib.lib().mvnerf_packed_net_split_bytes())
+            _chk(split[0], 'split_coarse', dtype=torch.uint8, shape=(nbytes,))
+            _chk(split[1], 'split_fine', dtype=torch.uint8, shape=(nbytes,))
+            rc = _lib.lib().mvnerf_render_fwd_split(_p(rays_o), _p(rays_d), _p(images), _p(features), _p(intrinsics),
+                                                    _p(extrinsics_inv), _p(packed_coarse), _p(packed_fine), _p(split[0]), _p(split[1]),
+                                                    _p(u_coarse), _p(u_fine), b, v, r, s, h, w, float(near), float(far),
+                                                    int(q7_mode), _p(rgb), _p(depth), _p(fine_rgb), _p(fine_depth), _p(workspace),
+                                                    _p(texel_tables), int(bool(tables_ready)), _stream(rays_o))
     _lib.check(rc, 'render_fwd')
     return rgb, depth, fine_rgb, fine_depth
 
