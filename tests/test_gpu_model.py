@@ -106,3 +106,51 @@ def test_render_view_matches_oracle():
     rgb8c, _ = render_view(m, src_colors, cfgs, tgt, combined_features=dev(feats), chunk=100,
                            generator=torch.Generator(device=DEV).manual_seed(0))
     assert rgb8c.shape == rgb8.shape
+
+
+def test_train_step_trains_the_feature_producer_end_to_end():
+    """the reference's encoder prologue (encoders.FeatureProducer = VisualFeatures + CombineCLIPVisualV0 shape) in
+    front of the HIP render path; `train_step` hands dL/d(combined_features) back to autograd.  The weight gradients of the
+    conv encoder and of the ViT side equal autograd through the float64 twin of the whole chain (producer in float64 on the
+    CPU -> oracle/mvnerf_torch.render_call), and the producer's own optimizer (Adam, 1e-5 warm-up group) moves its weights."""
+    import copy
+    from oracle import mvnerf_torch as T
+    from thesis_clip_nerf_amd import encoders as E
+    from thesis_clip_nerf_amd.synthetic import make_scene
+    tiny = dict(transformer_image_size=(32, 32), patch_size=16, embed_dim=32, num_heads=4, hooks=(1, 2, 3, 4), features=(4, 8, 16, 32))
+    sc = make_scene(seed=85, batch=1, n_views=2, height=16, width=24, n_rays=32, bias_scale=0.05)
+    y = np.random.default_rng(4).random((1, 32, 3)).astype(np.float32)
+    torch.manual_seed(0)
+    prod = E.FeatureProducer(original_image_size=(16, 24), **tiny).to(DEV)
+    twin = copy.deepcopy(prod).double().cpu()
+    m = MVVNeRFRenderer(32, 32, n_views=2, batch_size=1, near=sc['near'], far=sc['far'], device=DEV, feature_encoder=prod)
+    m.set_weights(sc['coarse'], sc['fine'])
+    opt, sched = E.make_encoder_optimizer(prod, target_lr=1e-3, warmup_steps=1)
+    m.compile(learning_rate=0.0, encoder_optimizer=opt)
+    inputs = tuple(sc[k] for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'])
+    before = [p.detach().clone() for p in prod.trainable_parameters()]
+    m.train_step((inputs, y), u_coarse=dev(sc['u_coarse']), u_fine=dev(sc['u_fine']), stop_fine_z=True)      # lr(0) = 0: gradients only
+    torch.cuda.synchronize()
+    got = {n: p.grad.double().cpu().clone() for n, p in prod.named_parameters() if p.grad is not None}
+    # float64 twin of the whole chain
+    t = lambda k: torch.as_tensor(sc[k]).double()
+    imgs = t('images')
+    feats = twin(imgs.reshape(2, 16, 24, 3)).reshape(1, 2, 16, 24, 256)
+    out = T.render_call(t('coarse'), t('fine'), t('rays_o'), t('rays_d'), imgs, t('intrinsics'), t('extrinsics_inv'), feats,
+                        sc['near'], sc['far'], sc['n_samples'], t('u_coarse'), t('u_fine'), stop_fine_z=True)
+    yy = torch.as_tensor(y).double()
+    (((yy - out[0]) ** 2).mean() + ((yy - out[2]) ** 2).mean()).backward()
+    checked = 0
+    for n, p in twin.named_parameters():
+        if p.grad is None or n not in got or p.grad.norm() == 0:
+            continue
+        ref = p.grad.clamp(-1.0, 1.0)                                  # train_step clips by value before the optimizer step
+        rel = float((got[n] - ref).norm() / ref.norm())
+        assert rel < 2e-2, (n, rel)                                    # fp32 producer + fp32 HIP backward vs float64
+        checked += 1
+    assert checked >= 20
+    assert all(torch.equal(a, b) for a, b in zip(before, prod.trainable_parameters()))       # lr was 0 at iteration 0 ...
+    sched.step()
+    m.train_step((inputs, y), u_coarse=dev(sc['u_coarse']), u_fine=dev(sc['u_fine']), stop_fine_z=True)
+    assert any(not torch.equal(a, b) for a, b in zip(before, prod.trainable_parameters()))  # ... and is not after the warm-up step
+    assert torch.equal(prod.combine_clip_visual.conv.weight, twin.combine_clip_visual.conv.weight.float().to(DEV))  # not in the optimizer list (Q9)

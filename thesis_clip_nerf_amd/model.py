@@ -280,7 +280,14 @@ class MVVNeRFRenderer:
             loss, grad, _, d_feat = self.loss_and_grads(inputs, labels, combined_features.detach().contiguous(), u_coarse, u_fine,
                                                         generator, stop_fine_z, return_d_features=True)
             enc_opt.zero_grad(set_to_none=True)
-            combined_features.backward(d_feat)
+            combined_features.backward(d_feat.to(combined_features.dtype))
+            if self._grad_sync is not None:              # data parallel: the encoder's gradients ride in ONE more flat collective
+                grads = [prm.grad for group in enc_opt.param_groups for prm in group['params'] if prm.grad is not None]
+                if grads:
+                    flat = torch._utils._flatten_dense_tensors(grads)
+                    self._grad_sync(flat)
+                    for g_, f_ in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+                        g_.copy_(f_)
             for group in enc_opt.param_groups:           # optimize(): clip-by-value, then the optimizer step
                 for prm in group['params']:
                     if prm.grad is not None:
