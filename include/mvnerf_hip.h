@@ -233,6 +233,12 @@ int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const floa
                             const float* features, const float* texel_table, const float* intrinsics,
                             const float* extrinsics_inv, const float* packed_net, int B, int V, int R, int S, int H, int W,
                             float* rgbs, float* stash, void* workspace, mvnerf_stream_t stream);
+/* mvnerf_field_eval_stash with the Dense layers as split-bf16 MFMA products (mvnerf_field_eval_split): same stash layout,
+ * consumed by the same mvnerf_field_backward. */
+int mvnerf_field_eval_stash_split(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                                  const float* features, const float* texel_table, const float* intrinsics,
+                                  const float* extrinsics_inv, const float* packed_net, const void* packed_split, int B, int V, int R,
+                                  int S, int H, int W, float* rgbs, float* stash, void* workspace, mvnerf_stream_t stream);
 
 /* The 12 hidden Dense kernels of one MLP and the three 128-row slabs of the layer-0 kernel, transposed, in
  * weight-stream order (15 x 16384 floats), for the dX GEMMs of the backward pass.

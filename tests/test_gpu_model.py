@@ -145,6 +145,9 @@ def test_train_step_trains_the_feature_producer_end_to_end():
         if p.grad is None or n not in got or p.grad.norm() == 0:
             continue
         ref = p.grad.clamp(-1.0, 1.0)                                  # train_step clips by value before the optimizer step
+        if ref.norm() < 1e-7:                                          # e.g. a conv bias in front of a batch-statistics BatchNorm:
+            assert got[n].norm() < 1e-5, (n, float(got[n].norm()))     # its gradient is exactly zero, fp32 leaves rounding noise
+            continue
         rel = float((got[n] - ref).norm() / ref.norm())
         assert rel < 2e-2, (n, rel)                                    # fp32 producer + fp32 HIP backward vs float64
         checked += 1

@@ -86,3 +86,38 @@ def test_render_fwd_split_matches_oracle(n_views, tables):
         err = np.abs(g[:, sub].cpu().numpy() - r).max()
         print(f'render split V={n_views} tables={tables} {name}: max|hip - oracle| = {err:.2e}')
         assert err < 1e-4, (name, err)                                              # north_star bar, fp32
+
+
+@pytest.mark.parametrize('views,table', [(1, True), (2, False), (3, True)])
+def test_stash_of_split_forward_matches_fp32_stash(views, table):
+    """Training forward on the split kernel: the 14 pre-activation slots it leaves in HBM (tile layout) against the fp32-MFMA
+    kernel's, same per-sample outputs - the backward consumes either."""
+    sc = make_scene(seed=3, n_views=views, height=16, width=16, n_rays=24, bias_scale=0.05)
+    d = {k: dev(sc[k]) for k in ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'u_coarse', 'coarse']}
+    z = ops.stratified_depths(d['u_coarse'], sc['near'], sc['far'])
+    packed, split = ops.pack_net(d['coarse']), ops.pack_net_split(d['coarse'])
+    tab = ops.project_texels(d['features'], packed) if table else None
+    args = (d['rays_o'], d['rays_d'], z, d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'], packed)
+    rgbs32, stash32 = ops.field_eval_stash(*args, texel_table=tab)
+    rgbs, stash = ops.field_eval_stash(*args, texel_table=tab, packed_split=split)
+    torch.cuda.synchronize()
+    n = ops.stash_bytes(1, views, 24, 64) // 4
+    a, b = stash.view(torch.float32)[:n], stash32.view(torch.float32)[:n]
+    assert (rgbs - rgbs32).abs().max().item() < 1e-5
+    assert (a - b).abs().max().item() < 2e-5 * max(1.0, b.abs().max().item())
+
+
+def test_renderer_default_gemm_is_split_and_matches_mfma_f32():
+    from thesis_clip_nerf_amd import MVVNeRFRenderer
+    sc = make_scene(seed=71, height=16, width=16, n_rays=64, bias_scale=0.05)
+    inputs = tuple(sc[k] for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'])
+    outs = {}
+    for gemm in ('split_bf16', 'mfma_f32'):
+        m = MVVNeRFRenderer(64, 64, n_views=1, near=sc['near'], far=sc['far'], device=DEV, f32_gemm=gemm)
+        m.set_weights(sc['coarse'], sc['fine'])
+        outs[gemm] = m._call(inputs, 64, 1, sc['features'], u_coarse=dev(sc['u_coarse']), u_fine=dev(sc['u_fine']))
+    assert MVVNeRFRenderer(64, 64, device=DEV).f32_gemm == 'split_bf16'
+    for a, b in zip(outs['split_bf16'], outs['mfma_f32']):
+        assert float((a - b).abs().max()) < 2e-5
+    with pytest.raises(ValueError):
+        MVVNeRFRenderer(64, 64, f32_gemm='tf32')

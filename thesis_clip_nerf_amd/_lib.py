@@ -60,6 +60,7 @@ SIGNATURES = {
     'mvnerf_stash_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'mvnerf_field_backward_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'mvnerf_field_eval_stash': (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_void_p] * 4),
+    'mvnerf_field_eval_stash_split': (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_void_p] * 4),
     'mvnerf_pack_bwd_streams': (c_int, [c_void_p, c_void_p, c_void_p]),
     'mvnerf_mse_grad': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     'mvnerf_composite_bwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p, c_void_p, c_void_p]),

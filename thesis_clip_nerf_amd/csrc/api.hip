@@ -389,6 +389,36 @@ int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const floa
     return hip_status(mvnerf::launch_field_eval(p, static_cast<hipStream_t>(stream)), "mvnerf_field_eval_stash");
 }
 
+int mvnerf_field_eval_stash_split(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                                  const float* features, const float* texel_table, const float* intrinsics,
+                                  const float* extrinsics_inv, const float* packed_net, const void* packed_split, int B, int V, int R,
+                                  int S, int H, int W, float* rgbs, float* stash, void* workspace, mvnerf_stream_t stream) {
+    if (texel_table && !aligned16(texel_table)) return fail(MVNERF_E_ALIGN, "mvnerf_field_eval_stash_split: texel_table must be 16-byte aligned");
+    if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !packed_net || !packed_split || !rgbs || !stash || !workspace)
+        return fail(MVNERF_E_ARG, "mvnerf_field_eval_stash_split: null pointer");
+    if (B <= 0 || V <= 0 || R <= 0 || S <= 0 || H < 2 || W < 2) return fail(MVNERF_E_ARG, "mvnerf_field_eval_stash_split: B=%d V=%d R=%d S=%d H=%d W=%d", B, V, R, S, H, W);
+    if (V > 1 && ((long)R * S) % 32 != 0) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_stash_split: R*S=%ld must be a multiple of 32 when V > 1", (long)R * S);
+    const long total = (long)B * R * S;
+    if (total >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_stash_split: B*R*S too large");
+    if ((long)V * ((total + 31) / 32) >= (1L << 18))      // stash slots are addressed with 32-bit byte offsets (16 KiB per tile)
+        return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_stash_split: V*B*R*S/32 = %ld tiles per stash slot, at most 262143", (long)V * ((total + 31) / 32));
+    if (!aligned16(features) || !aligned16(packed_net) || !aligned16(packed_split) || !aligned16(rgbs) || !aligned16(stash) || !aligned16(workspace))
+        return fail(MVNERF_E_ALIGN, "mvnerf_field_eval_stash_split: features, packed nets, rgbs, stash, workspace must be 16-byte aligned");
+    mvnerf::FieldParams p = {};
+    p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.images = images; p.features = features;
+    p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs;
+    p.texel_table = texel_table;
+    p.dir_bias = static_cast<float*>(workspace);
+    p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W;
+    p.total = total;
+    p.n_tiles = (total + 31) / 32;
+    p.stash = stash;
+    p.stash_stride = (long)V * p.n_tiles * 4096;
+    p.stash_fused = stash + 7 * p.stash_stride;
+    p.stash_fused_stride = p.n_tiles * 4096;
+    return hip_status(mvnerf::launch_field_eval_split(p, packed_split, static_cast<hipStream_t>(stream)), "mvnerf_field_eval_stash_split");
+}
+
 int mvnerf_pack_bwd_streams(const float* net_keras, float* bwd_streams, mvnerf_stream_t stream) {
     if (!net_keras || !bwd_streams) return fail(MVNERF_E_ARG, "mvnerf_pack_bwd_streams: null pointer");
     if (!aligned16(bwd_streams)) return fail(MVNERF_E_ALIGN, "mvnerf_pack_bwd_streams: bwd_streams must be 16-byte aligned");

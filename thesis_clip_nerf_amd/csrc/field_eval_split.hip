@@ -383,7 +383,8 @@ __device__ __forceinline__ void bias_acc(const float* __restrict__ bperm, int h,
 constexpr int kStageRowBytes = 256;      // per staged sample row: 64 fp32 channels
 
 // kProj: layer 0's feature rows come from the fp32 texel table (project_texels_kernel, field_eval.hip).
-template <bool kMultiView, bool kProj>
+// kStash (training forward): the trunk's pre-activations go to HBM in tile layout, as field_eval_kernel<.., kStash> does.
+template <bool kMultiView, bool kProj, bool kStash>
 __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(FieldParams p, const f32x4* __restrict__ wsplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sp[];
     constexpr int kRingBytes = kRing * kSlotF4 * 16;                        // 36 KiB
@@ -607,14 +608,19 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
 
             const long vslot = (long)p.B * p.V * p.R * p.S * 128;
             if (p.acts_view && valid) store_row(p.acts_view + 128 * vrow);
+            // training mode: view tile index (all 32 samples of a tile share b because R*S % 32 == 0 when V > 1)
+            const long vtile = kMultiView ? ((long)bv * (p.n_tiles / p.B) + (tile - (long)b * (p.n_tiles / p.B))) : tile;
+            if (kStash && tile_ok) store_tl(p.stash, vtile, j, h, x);                       // per-view slot 0: layer-0 output
             // ---- 48 k-steps: the three per-view ResNet blocks ----
 #pragma unroll 1
             for (int bi = 0; bi < 3; ++bi) {
                 const float* bias1 = net + kPackBHidden + 256 * bi;
                 bias_acc<false>(bias1, h, hid);
                 dense128_split(ring, lane, x, hid);
+                if (kStash && tile_ok) store_tl(p.stash + (1 + 2 * bi) * p.stash_stride, vtile, j, h, hid);
                 bias_acc<true>(bias1 + 128, h, x);
                 dense128_split(ring, lane, hid, x);
+                if (kStash && tile_ok) store_tl(p.stash + (2 + 2 * bi) * p.stash_stride, vtile, j, h, x);
                 if (p.acts_view && valid) store_row(p.acts_view + (bi + 1) * vslot + 128 * vrow);
             }
             if (kMultiView) {
@@ -629,14 +635,17 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
         }
 
         if (p.acts_fused && valid) store_row(p.acts_fused + 128 * g);       // complete_output: the view mean
+        if (kStash && tile_ok) store_tl(p.stash_fused, tile, j, h, x);       // fused slot 0: the view mean
         // ---- 48 k-steps: fusion blocks ----
 #pragma unroll 1
         for (int bi = 3; bi < 6; ++bi) {
             const float* bias1 = net + kPackBHidden + 256 * bi;
             bias_acc<false>(bias1, h, hid);
             dense128_split(ring, lane, x, hid);
+            if (kStash && tile_ok) store_tl(p.stash_fused + (1 + 2 * (bi - 3)) * p.stash_fused_stride, tile, j, h, hid);
             bias_acc<true>(bias1 + 128, h, x);
             dense128_split(ring, lane, hid, x);
+            if (kStash && tile_ok) store_tl(p.stash_fused + (2 + 2 * (bi - 3)) * p.stash_fused_stride, tile, j, h, x);
             if (p.acts_fused && valid) store_row(p.acts_fused + (long)(bi - 2) * p.total * 128 + 128 * g);
         }
         if (p.embedding && valid) store_row(p.embedding + 128 * g);
@@ -723,10 +732,14 @@ hipError_t launch_field_eval_split(const FieldParams& p, const void* packed_spli
             hipDeviceProp_t prop;
             if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
             cus[dev] = prop.multiProcessorCount;
-            const void* fns[4] = {reinterpret_cast<const void*>(&field_eval_split_kernel<false, false>),
-                                  reinterpret_cast<const void*>(&field_eval_split_kernel<false, true>),
-                                  reinterpret_cast<const void*>(&field_eval_split_kernel<true, false>),
-                                  reinterpret_cast<const void*>(&field_eval_split_kernel<true, true>)};
+            const void* fns[8] = {reinterpret_cast<const void*>(&field_eval_split_kernel<false, false, false>),
+                                  reinterpret_cast<const void*>(&field_eval_split_kernel<false, true, false>),
+                                  reinterpret_cast<const void*>(&field_eval_split_kernel<true, false, false>),
+                                  reinterpret_cast<const void*>(&field_eval_split_kernel<true, true, false>),
+                                  reinterpret_cast<const void*>(&field_eval_split_kernel<false, false, true>),
+                                  reinterpret_cast<const void*>(&field_eval_split_kernel<false, true, true>),
+                                  reinterpret_cast<const void*>(&field_eval_split_kernel<true, false, true>),
+                                  reinterpret_cast<const void*>(&field_eval_split_kernel<true, true, true>)};
             for (const void* fn : fns)
                 if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess) return e;
             attr_done[dev] = true;
@@ -737,13 +750,21 @@ hipError_t launch_field_eval_split(const FieldParams& p, const void* packed_spli
     const long resident = (long)cus[dev];                                   // persistent: one workgroup per CU
     const unsigned wgs = (unsigned)(n_groups < resident ? n_groups : resident);
     const f32x4* w = static_cast<const f32x4*>(packed_split);
-    if (p.V > 1) {
-        if (p.texel_table) hipLaunchKernelGGL((field_eval_split_kernel<true, true>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w);
-        else hipLaunchKernelGGL((field_eval_split_kernel<true, false>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w);
-    } else {
-        if (p.texel_table) hipLaunchKernelGGL((field_eval_split_kernel<false, true>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w);
-        else hipLaunchKernelGGL((field_eval_split_kernel<false, false>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w);
+    if (p.stash && p.V > 1 && ((long)p.R * p.S) % 32 != 0) return hipErrorInvalidValue;     // tiles must not straddle scenes
+    const dim3 grid(wgs), block(64 * kWgWaves);
+#define MVS_LAUNCH(MV, PROJ, STASH) hipLaunchKernelGGL((field_eval_split_kernel<MV, PROJ, STASH>), grid, block, lds_bytes, stream, p, w)
+    const int variant = (p.V > 1 ? 4 : 0) + (p.texel_table ? 2 : 0) + (p.stash ? 1 : 0);
+    switch (variant) {
+        case 0: MVS_LAUNCH(false, false, false); break;
+        case 1: MVS_LAUNCH(false, false, true); break;
+        case 2: MVS_LAUNCH(false, true, false); break;
+        case 3: MVS_LAUNCH(false, true, true); break;
+        case 4: MVS_LAUNCH(true, false, false); break;
+        case 5: MVS_LAUNCH(true, false, true); break;
+        case 6: MVS_LAUNCH(true, true, false); break;
+        default: MVS_LAUNCH(true, true, true); break;
     }
+#undef MVS_LAUNCH
     return hipGetLastError();
 }
 

@@ -235,11 +235,12 @@ class MVVNeRFRenderer:
             if tb.get('tables') is None or tuple(tb['tables'].shape[1:]) != tuple(feats.shape[:4]) + (128,):
                 tb['tables'] = torch.empty((2,) + tuple(feats.shape[:4]) + (128,), dtype=torch.float32, device=self.device)
             tab_c, tab_f = ops.project_texels2(feats, pc, pf, out=tb['tables']).unbind(0)
+        sp_c, sp_f = self.packed_split() if self.f32_gemm == 'split_bf16' else (None, None)
         z = ops.stratified_depths(self._dev(u_coarse), self.near, self.far)
-        rgbs_c, tb['stash_c'] = ops.field_eval_stash(rays_o, rays_d, z, *geo, pc, tb.get('stash_c'), texel_table=tab_c)
+        rgbs_c, tb['stash_c'] = ops.field_eval_stash(rays_o, rays_d, z, *geo, pc, tb.get('stash_c'), texel_table=tab_c, packed_split=sp_c)
         rgb, depth, w = ops.composite(z, rgbs_c)
         z_all, rank = ops.resample(z, w, self._dev(u_fine), self.q7_mode, return_rank=True)
-        rgbs_f, tb['stash_f'] = ops.field_eval_stash(rays_o, rays_d, z_all, *geo, pf, tb.get('stash_f'), texel_table=tab_f)
+        rgbs_f, tb['stash_f'] = ops.field_eval_stash(rays_o, rays_d, z_all, *geo, pf, tb.get('stash_f'), texel_table=tab_f, packed_split=sp_f)
         fine_rgb, fine_depth, _ = ops.composite(z_all, rgbs_f, return_weights=False)
         # loss and its gradient w.r.t. the two rendered images
         loss = torch.zeros(1, dtype=torch.float32, device=self.device)

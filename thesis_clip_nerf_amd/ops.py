@@ -435,8 +435,10 @@ def stash_bytes(b, v, r, s):
     return int(_lib.lib().mvnerf_stash_bytes(int(b), int(v), int(r), int(s)))
 
 
-def field_eval_stash(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, stash=None, texel_table=None):
-    """Training-mode field pass: -> (rgbs (B,R,S,4), stash uint8 tensor with the trunk pre-activations)."""
+def field_eval_stash(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, stash=None, texel_table=None,
+                     packed_split=None):
+    """Training-mode field pass: -> (rgbs (B,R,S,4), stash uint8 tensor with the trunk pre-activations).
+    packed_split: pack_net_split(net) -> the split-bf16 kernel (mvnerf_field_eval_stash_split), same stash."""
     _chk(rays_o, 'rays_o', shape=(None, None, 3))
     b, r, _ = rays_o.shape
     _chk(rays_d, 'rays_d', shape=(b, r, 3))
@@ -457,9 +459,15 @@ def field_eval_stash(rays_o, rays_d, z, images, features, intrinsics, extrinsics
     with torch.cuda.device(dev):
         if texel_table is not None:
             _chk(texel_table, 'texel_table', shape=(b, v, h, w, 128))
-        rc = _lib.lib().mvnerf_field_eval_stash(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(texel_table),
-                                                _p(intrinsics), _p(extrinsics_inv), _p(packed_net), b, v, r, s, h, w, _p(rgbs),
-                                                _p(stash), _p(ws), _stream(rays_o))
+        if packed_split is None:
+            rc = _lib.lib().mvnerf_field_eval_stash(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(texel_table),
+                                                    _p(intrinsics), _p(extrinsics_inv), _p(packed_net), b, v, r, s, h, w, _p(rgbs),
+                                                    _p(stash), _p(ws), _stream(rays_o))
+        else:
+            _chk(packed_split, 'packed_split', dtype=torch.uint8, shape=(int(_lib.lib().mvnerf_packed_net_split_bytes()),))
+            rc = _lib.lib().mvnerf_field_eval_stash_split(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(texel_table),
+                                                          _p(intrinsics), _p(extrinsics_inv), _p(packed_net), _p(packed_split), b, v, r, s,
+                                                          h, w, _p(rgbs), _p(stash), _p(ws), _stream(rays_o))
     _lib.check(rc, 'field_eval_stash')
     return rgbs, stash
 
