@@ -108,7 +108,14 @@ hipError_t launch_pack_net_bf16(const float* net_keras, void* packed16, hipStrea
 constexpr int kWgWaves = MV16_WAVES;
 constexpr int kSegChunks = 2 * kWgWaves;                       // 16 or 8 chunks of 1 KiB
 constexpr int kKs = kSegChunks / 4;                            // k-steps (of 16 rows) per segment: 4 or 2
+#ifndef MV16_LDSDMA
+#define MV16_LDSDMA 1      // 1: LDS-DMA ring of 5 slots (default); 0: register-staged double buffer (round 2 A/B: equal at cfg2, 14 % slower at V = 3)
+#endif
+#if MV16_LDSDMA
 constexpr int kRing = 5, kAhead = 3, kSegF4 = kSegChunks * 64;  // float4 per slot
+#else
+constexpr int kRing = 2, kSegF4 = kSegChunks * 64;              // float4 per slot
+#endif
 constexpr int kHiddenUnits = 192 / kSegChunks;                 // segments of 3 blocks (6 Dense layers x 32 chunks)
 
 struct Ring {
@@ -118,6 +125,9 @@ struct Ring {
     int p, P, V;
     int l0_units;       // layer-0 segments per view: PE + rgb only (texel table) or PE + rgb + 256 feature rows
     int tid, wave;
+#if !MV16_LDSDMA
+    f32x4 stg0, stg1;   // the next segment on its way to LDS (2 x 16 B per thread)
+#endif
 };
 
 __device__ __forceinline__ int ring_start_chunk(int p, int V, int l0_units) {
@@ -130,6 +140,7 @@ __device__ __forceinline__ int ring_start_chunk(int p, int V, int l0_units) {
     return q < kHiddenUnits ? kW16Hidden + 192 + q * kSegChunks : kW16Readout;
 }
 
+#if MV16_LDSDMA
 // issue the LDS-DMA of position p + ahead into slot (c + ahead) % kRing: 2 x 16 B per thread, 1 KiB per wave-instruction
 __device__ __forceinline__ void ring_issue(const Ring& r, int ahead) {
     int pp = r.p + ahead;
@@ -160,6 +171,39 @@ __device__ __forceinline__ void ring_next(Ring& r) {
     r.p = r.p + 1 == r.P ? 0 : r.p + 1;
     if (!MV16_ABL_DMA) ring_issue(r, kAhead);          // slot (c + 3) % 5 was last read two segments ago; everyone is past that barrier
 }
+#else
+// Weight stream through registers (round 2): a CU accepts only about one 1 KiB LDS-DMA instruction per ~110 cycles
+// (field_eval_split.hip, in-kernel stamps; MI355X_MICROARCH.md: ~25 GB/s per CU for LDS-DMA fills) - the 480 DMA
+// instructions of one 8-tile group cost about twice the group's matrix time.  Here every thread loads 2 x 16 B of the NEXT
+// segment right after a barrier and stores them to the other LDS slot just before the following barrier: the vector-memory
+// path moves the same bytes at 64 B/clk, a segment of matrix work lies between a load and the store that waits for it, and
+// two slots (instead of five) are enough.
+__device__ __forceinline__ void ring_load(Ring& r, int pp) {                      // position pp -> staging registers
+    if (pp >= r.P) pp -= r.P;
+    const f32x4* src = r.w16 + (long)ring_start_chunk(pp, r.V, r.l0_units) * 64 + r.tid;
+    r.stg0 = src[0];
+    r.stg1 = src[64 * kWgWaves];
+}
+
+__device__ __forceinline__ const f32x4* ring_cur(const Ring& r) { return r.base + r.c * kSegF4; }
+
+template <bool kDrain>
+__device__ __forceinline__ void ring_next(Ring& r) {
+    f32x4* dst = r.base + (r.c ^ 1) * kSegF4 + r.tid;                             // position p + 1, loaded during this segment
+    if (!MV16_ABL_DMA) {
+        dst[0] = r.stg0;
+        dst[64 * kWgWaves] = r.stg1;
+    }
+#if MV16_ABL_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+    r.c ^= 1;
+    r.p = r.p + 1 == r.P ? 0 : r.p + 1;
+    if (!MV16_ABL_DMA) ring_load(r, r.p + 1);
+}
+#endif
 
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -359,11 +403,19 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_bf16_kernel(Field
     ring.P = (ring.l0_units + kHiddenUnits) * p.V + kHiddenUnits + 1;
     ring.tid = tid;
     ring.wave = wave;
+#if MV16_LDSDMA
     ring_issue(ring, 0);
     ring_issue(ring, 1);
     ring_issue(ring, 2);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     ring_issue(ring, kAhead);
+#else
+    ring_load(ring, 0);
+    ring.base[tid] = ring.stg0;                                            // position 0 -> slot 0
+    ring.base[tid + 64 * kWgWaves] = ring.stg1;
+    ring_load(ring, 1);
+    __syncthreads();
+#endif
 
     const long n_groups = (p.n_tiles + kWgWaves - 1) / kWgWaves;
     for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
