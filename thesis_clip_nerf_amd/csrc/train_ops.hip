@@ -133,6 +133,38 @@ hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int 
 // workgroup's tiles and adding it once at the end.
 __device__ __forceinline__ int swz_f4(int f, int chunk) { return f * 8 + (chunk ^ (f & 7)); }     // float4 index
 
+#ifndef MVT_SPLIT_DW
+#define MVT_SPLIT_DW 1     // weight-gradient GEMM (samples are K) as six bf16 MFMAs per product on exactly cut operands
+#endif                     // (fp32-grade, see field_eval_split.hip) instead of v_mfma_f32_32x32x2_f32: 48 x 32 instead of 64 x 64 matrix cycles per tile
+
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned int;
+
+__device__ __forceinline__ f32x16 mfma16s(u32x4_t a, u32x4_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// exact cut of 8 fp32 values (two float4) into three bf16 pieces each (truncation; remainders are exact fp32 subtractions)
+template <bool kRelu>
+__device__ __forceinline__ void cut3(const f32x4& lo, const f32x4& hi, u32x4_t& p1, u32x4_t& p2, u32x4_t& p3) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v0 = q < 2 ? lo[2 * q] : hi[2 * q - 4], v1 = q < 2 ? lo[2 * q + 1] : hi[2 * q - 3];
+        if (kRelu) {
+            const int i0 = __builtin_bit_cast(int, v0), i1 = __builtin_bit_cast(int, v1);
+            v0 = __builtin_bit_cast(float, i0 > 0 ? i0 : 0);
+            v1 = __builtin_bit_cast(float, i1 > 0 ? i1 : 0);
+        }
+        const float r0 = v0 - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v0) & 0xffff0000u);
+        const float r1 = v1 - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v1) & 0xffff0000u);
+        const float s0 = r0 - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r0) & 0xffff0000u);
+        const float s1 = r1 - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & 0xffff0000u);
+        p1[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, v1), __builtin_bit_cast(unsigned, v0), 0x07060302u);
+        p2[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, r1), __builtin_bit_cast(unsigned, r0), 0x07060302u);
+        p3[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+    }
+}
+
 template <bool kDW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_bwd_fused_kernel(const float* __restrict__ g_tl, const float* __restrict__ a_tl,
                                                                  const float* __restrict__ wstream,
@@ -215,8 +247,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float gcur[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) gcur[e] = sGf[gbase[e]];
+#if !MVT_SPLIT_DW
         f32x4 a4[4];
+#endif
         f32x4 dgcur = sG[tbase[0]];
+#if MVT_SPLIT_DW
+        // dW rows of block w on the bf16 matrix pipe: K = the tile's 32 samples = 2 k-steps of 16; lane (i, h) supplies samples
+        // 16 ks + 8 h + {0..7} of row 32 w + i of relu(a) (A operand) and of row 32 nb + i of G (B operand): two float4 chunks
+        // of the staged rows each, cut into three bf16 pieces
+        u32x4_t ap[3], bp[3];
+#else
         if (kDW) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -225,6 +265,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int e = 0; e < 4; ++e) a4[t][e] = fmaxf(a4[t][e], 0.0f);
             }
         }
+#endif
         float sgsum = 0.0f;
 #pragma unroll
         for (int grp = 0; grp < 16; ++grp) {
@@ -237,6 +278,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int e = 0; e < 4; ++e)                                          // contraction index n = 32kb + 8t + 4h + e
                 gnext[e] = sGf[gbase[e] + (32 * (gn >> 2) + 8 * (gn & 3)) * 32];
             f32x4 dgnext = dgcur;
+#if MVT_SPLIT_DW
+            if (kDW && (grp & 7) == 0) {                                         // A pieces of k-step ks = grp / 8
+                const int ks = grp >> 3, row = 32 * w + i;
+                cut3<true>(sA[swz_f4(row, 4 * ks + 2 * h)], sA[swz_f4(row, 4 * ks + 2 * h + 1)], ap[0], ap[1], ap[2]);
+            }
+            if (kDW && (grp & 1) == 0) {                                         // pair q = grp / 2 -> (k-step ks = q / 4, output block nb = q % 4)
+                const int q = grp >> 1, row = 32 * (q & 3) + i, ks = q >> 2;
+                const f32x4 g_lo = sG[swz_f4(row, 4 * ks + 2 * h)], g_hi = sG[swz_f4(row, 4 * ks + 2 * h + 1)];
+                cut3<false>(g_lo, g_hi, bp[0], bp[1], bp[2]);
+                dbacc[q & 3] = dbacc[q & 3] + (((g_lo[0] + g_lo[1]) + (g_lo[2] + g_lo[3])) + ((g_hi[0] + g_hi[1]) + (g_hi[2] + g_hi[3])));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma(wcur[e], gcur[e], acc);
+            if (kDW && (grp & 1) == 1) {
+                const int nb = (grp >> 1) & 3;
+                dwacc[nb] = mfma16s(ap[2], bp[0], dwacc[nb]);
+                dwacc[nb] = mfma16s(ap[1], bp[1], dwacc[nb]);
+                dwacc[nb] = mfma16s(ap[0], bp[2], dwacc[nb]);
+                dwacc[nb] = mfma16s(ap[1], bp[0], dwacc[nb]);
+                dwacc[nb] = mfma16s(ap[0], bp[1], dwacc[nb]);
+                dwacc[nb] = mfma16s(ap[0], bp[0], dwacc[nb]);
+            }
+#else
             if (kDW) dgnext = sG[tbase[gn & 3] + 256 * (gn >> 2)];               // dW group = (output block nb = grp / 4, t = grp % 4)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -247,10 +312,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     sgsum = sgsum + dgcur[e];
                 }
             }
+#endif
+#if !MVT_SPLIT_DW
             if (kDW && (grp & 3) == 3) {
                 dbacc[grp >> 2] = dbacc[grp >> 2] + sgsum;
                 sgsum = 0.0f;
             }
+#endif
             wcur = wnxt;
             wnxt = wnext2;
             dgcur = dgnext;
