@@ -253,12 +253,20 @@ def main():
             'reference_flop_per_launch': fps_ref * b * r * 2 * s,
             'reference_equiv_tflops': ref_tflops, 'frac_reference_equiv': ref_tflops / peak,
         }
+        if split:
+            # the split kernel delivers fp32-grade products on the bf16 pipe: six MFMAs per fp32 product block.  `frac` above is
+            # the matrix-pipe utilisation (executed bf16 FLOPs / 2.5 PFLOP/s); this is the same launch measured in the
+            # reference graph's fp32 FLOPs against the fp32 MFMA peak the round-1 kernel was bound by
+            result['roofline']['reference_equiv_vs_fp32_mfma_peak'] = ref_tflops / PEAK_FP32_MFMA_TFLOPS
+            result['roofline']['arithmetic'] = ('fp32 operands cut exactly into 3 bf16 pieces, 6 v_mfma_f32_32x32x16_bf16 per product block, '
+                                                'fp32 accumulate (dropped terms <= 2^-24 relative)')
         if use_table:
             result['roofline']['project_texels_ms_per_step'] = float(np.mean([e[4].elapsed_time(e[5]) for e in ev]))
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(pmc) and not bf16 and not split and args.views == 1 and (img_h, img_w, r) == (64, 64, 4096):   # counters were collected on cfg2
+        if os.path.exists(pmc) and not bf16 and (use_table or not split) and args.views == 1 and (img_h, img_w, r) == (64, 64, 4096):   # counters were collected on cfg2
             try:
-                key = 'field_eval_table_fine_hbm_bytes_per_launch' if use_table else 'field_eval_fine_hbm_bytes_per_launch'
+                key = ('field_eval_split_table_fine_hbm_bytes_per_launch' if split else
+                       'field_eval_table_fine_hbm_bytes_per_launch' if use_table else 'field_eval_fine_hbm_bytes_per_launch')
                 counters = json.load(open(pmc))
                 result['roofline']['traffic'] = counters.get(key)
                 if counters.get(key):                  # rocprof counters (profiles/): HBM-side GB/s of this launch, matrix pipe busy

@@ -11,7 +11,7 @@ root = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
 for path in sorted(glob.glob(os.path.join(root, '*', '*', '*_counter_collection.csv'))):
     for row in csv.DictReader(open(path)):
-        k = row['Kernel_Name'].split('(')[0].replace('void ', '')
+        k = row['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
         key = (k, int(row['Grid_Size']) if 'Grid_Size' in row else int(row.get('Grid_Size_X', 0)))
         acc[key][row['Counter_Name']].append(float(row['Counter_Value']))
 print('| kernel | grid | counter | mean/dispatch | dispatches |')

@@ -11,7 +11,7 @@ acc = defaultdict(list)
 meta = {}
 for path in glob.glob(os.path.join(sys.argv[1], '**', '*_kernel_trace.csv'), recursive=True):
     for r in csv.DictReader(open(path)):
-        k = (r['Kernel_Name'].split('(')[0].replace('void ', ''), int(r['Grid_Size_X']), int(r['Workgroup_Size_X']))
+        k = (r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', ''), int(r['Grid_Size_X']), int(r['Workgroup_Size_X']))
         acc[k].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
         meta[k] = (r['VGPR_Count'], r['Accum_VGPR_Count'], r['SGPR_Count'], r['LDS_Block_Size'], r['Scratch_Size'])
 tot = sum(sum(v) for v in acc.values())
