@@ -266,3 +266,30 @@ def test_train_step_trains_an_upstream_torch_encoder():
     clip = lambda g: g.clamp(-1.0, 1.0)                    # train_step clips by value before the optimizer step
     assert (got_w - clip(W.grad)).norm() < 6e-3 * clip(W.grad).norm()
     assert (got_b - clip(bb.grad)).norm() < 6e-3 * clip(bb.grad).norm()
+
+
+def test_deterministic_weight_gradients_are_bit_identical_from_run_to_run():
+    """ops.set_deterministic: per-workgroup partials summed in workgroup order instead of fp32 atomics.  Two runs on the same
+    inputs give bit-identical weight gradients (the atomics mode does not promise that), and the two modes agree to rounding."""
+    sc = make_scene(seed=44, batch=1, n_views=1, height=32, width=32, bias_scale=0.05)          # 1024 rays: 2048 / 4096 tiles > 512 workgroups
+    y = np.random.default_rng(2).random((1, 1024, 3)).astype(np.float32)
+    m = MVVNeRFRenderer(1024, 1024, n_views=1, batch_size=1, near=sc['near'], far=sc['far'], device=DEV)
+    m.set_weights(sc['coarse'], sc['fine'])
+    inputs = tuple(sc[k] for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'])
+    kw = dict(u_coarse=dev(sc['u_coarse']), u_fine=dev(sc['u_fine']), stop_fine_z=True)      # (d_z accumulates with atomics only when V > 1)
+    prev = ops.set_deterministic(True)
+    try:
+        g1 = m.loss_and_grads(inputs, y, sc['features'], **kw)[1].clone()
+        g2 = m.loss_and_grads(inputs, y, sc['features'], **kw)[1].clone()
+        g3 = m.loss_and_grads(inputs, y, sc['features'], u_coarse=kw['u_coarse'], u_fine=kw['u_fine'])[1].clone()
+        g4 = m.loss_and_grads(inputs, y, sc['features'], u_coarse=kw['u_coarse'], u_fine=kw['u_fine'])[1].clone()
+    finally:
+        ops.set_deterministic(prev)
+    torch.cuda.synchronize()
+    assert torch.equal(g1, g2) and torch.equal(g3, g4)
+    ga = m.loss_and_grads(inputs, y, sc['features'], **kw)[1]
+    torch.cuda.synchronize()
+    assert torch.isfinite(g1).all() and g1.abs().max().item() > 0
+    assert ((ga - g1).norm() / g1.norm()).item() < 1e-5
+    m.compile(deterministic=True)
+    assert ops.set_deterministic(False) is True

@@ -5,6 +5,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/mvnerf_hip.h"
 #include "mvnerf_kernels.h"
 #include "mvnerf_math.h"
@@ -346,6 +348,7 @@ int mvnerf_finish_view(const float* rgb, const float* depth, long n, float* minm
 namespace {
 long tiles_for(int B, int R, int S) { return ((long)B * R * S + 31) / 32; }
 constexpr int kBwdMaxWGs = 512;      // resident workgroups of the dW kernels (2 per CU)
+static_assert(kBwdMaxWGs <= 512, "kPartialFloats is sized for 512 workgroups");
 constexpr int kFusedBwdWGs = 512;    // fused dX+dW kernel: 2 waves/SIMD by registers -> 2 resident workgroups per CU
 }  // namespace
 
@@ -354,10 +357,16 @@ size_t mvnerf_stash_bytes(int B, int V, int R, int S) {
     return (size_t)(7 * V + 7) * tiles_for(B, R, S) * 128 * 32 * sizeof(float);     // 7 per-view + 7 fused slots
 }
 
+// deterministic mode: per-workgroup partials of the largest weight-gradient span (layer 0: 379 x 128 + 128 floats)
+constexpr size_t kPartialFloats = (size_t)512 * (mvnerf::kIn * mvnerf::kHidden + mvnerf::kHidden);   // 512 = kBwdMaxWGs = kFusedBwdWGs
+std::atomic<int> g_deterministic{0};
+
 size_t mvnerf_field_backward_scratch_bytes(int B, int V, int R, int S) {
     if (B <= 0 || V <= 0 || R <= 0 || S <= 0) return 0;
-    return (size_t)tiles_for(B, R, S) * ((size_t)3 * V * 128 + 32) * 32 * sizeof(float);
+    return ((size_t)tiles_for(B, R, S) * ((size_t)3 * V * 128 + 32) * 32 + kPartialFloats) * sizeof(float);
 }
+
+int mvnerf_set_deterministic(int on) { return g_deterministic.exchange(on ? 1 : 0); }
 
 int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const float* z, const float* images,
                             const float* features, const float* texel_table, const float* intrinsics,
@@ -470,13 +479,14 @@ int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float*
     const size_t vslot = (size_t)view_tiles * 4096, fslot = (size_t)n_tiles * 4096;
     float* buf[3] = {static_cast<float*>(scratch), static_cast<float*>(scratch) + vslot, static_cast<float*>(scratch) + 2 * vslot};
     float* do_tl = static_cast<float*>(scratch) + 3 * vslot;
+    float* part = g_deterministic.load() ? do_tl + (size_t)n_tiles * 32 * 32 : nullptr;   // per-workgroup partials (deterministic mode)
     auto view_slot = [&](int k) { return stash + (size_t)k * vslot; };                   // x0,h1,x1,h2,x2,h3,x3
     auto fused_slot = [&](int m) { return stash + 7 * vslot + (size_t)m * fslot; };      // mean,h4,x4,h5,x5,h6,x6
     hipError_t e;
 #define MV_TRY(call) if ((e = (call)) != hipSuccess) return hip_status(e, "mvnerf_field_backward")
     // read-out
     MV_TRY(launch_readout_bwd(fused_slot(6), rgbs, d_rgbs, net_keras + kKerasWr, total, n_tiles, do_tl, buf[0], st));
-    MV_TRY(launch_dw_tile(fused_slot(6), 1, do_tl, 32, n_tiles, grad + kKerasWr, 4, 4, grad + kKerasBr, kBwdMaxWGs, st));
+    MV_TRY(launch_dw_tile(fused_slot(6), 1, do_tl, 32, n_tiles, grad + kKerasWr, 4, 4, grad + kKerasBr, kBwdMaxWGs, part, st));
     int g = 0;                                         // buf[g] holds dL/d(block output)
     for (int bi = 5; bi >= 0; --bi) {
         if (bi == 2 && V > 1) {                        // reduce_mean over views (layers.py:368-370)
@@ -492,10 +502,10 @@ int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float*
         const int dh = (g + 1) % 3, gn = (g + 2) % 3;
         // second Dense of the block: out = x_in + W2^T relu(hid) + b2      (dX and dW in one pass over the tiles)
         MV_TRY(launch_dense_bwd_fused(buf[g], pre_hid, bwd_streams + (size_t)(2 * bi + 1) * kHiddenWFloats, nullptr, buf[dh], nt,
-                                      gb + kHidden * kHidden + kHidden, gb + 2 * kHidden * kHidden + kHidden, kFusedBwdWGs, st));
+                                      gb + kHidden * kHidden + kHidden, gb + 2 * kHidden * kHidden + kHidden, kFusedBwdWGs, part, st));
         // first Dense: hid = W1^T relu(x_in) + b1 ; the identity branch adds dL/d(out) back
         MV_TRY(launch_dense_bwd_fused(buf[dh], pre_in, bwd_streams + (size_t)(2 * bi) * kHiddenWFloats, buf[g], buf[gn], nt, gb,
-                                      gb + kHidden * kHidden, kFusedBwdWGs, st));
+                                      gb + kHidden * kHidden, kFusedBwdWGs, part, st));
         g = gn;
     }
     // layer 0 (inputs recomputed)
@@ -503,7 +513,7 @@ int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float*
     p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.images = images; p.features = features;
     p.k4 = intrinsics; p.einv = extrinsics_inv;
     p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W; p.total = total; p.n_tiles = n_tiles;
-    MV_TRY(launch_dw0(p, buf[g], grad + kKerasW0, grad + kKerasB0, kBwdMaxWGs, st));
+    MV_TRY(launch_dw0(p, buf[g], grad + kKerasW0, grad + kKerasB0, kBwdMaxWGs, part, st));
     if (d_z || d_features)
         MV_TRY(launch_field_dz(p, buf[g], bwd_streams + (size_t)12 * kHiddenWFloats, d_z, nullptr, nullptr, d_features, st));
 #undef MV_TRY
@@ -583,9 +593,9 @@ int mvnerf_query_vjp(const float* points, const float* dirs, const float* images
         const float* pre_hid = fused ? fused_slot(2 * (bi - 3) + 1) : view_slot(2 * bi + 1);
         const int dh = (g + 1) % 3, gn = (g + 2) % 3;
         MV_TRY(launch_dense_bwd_fused(buf[g], pre_hid, bwd_streams + (size_t)(2 * bi + 1) * kHiddenWFloats, nullptr, buf[dh], nt,
-                                      nullptr, nullptr, kFusedBwdWGs, st));
+                                      nullptr, nullptr, kFusedBwdWGs, nullptr, st));
         MV_TRY(launch_dense_bwd_fused(buf[dh], pre_in, bwd_streams + (size_t)(2 * bi) * kHiddenWFloats, buf[g], buf[gn], nt,
-                                      nullptr, nullptr, kFusedBwdWGs, st));
+                                      nullptr, nullptr, kFusedBwdWGs, nullptr, st));
         g = gn;
         if (fused) MV_TRY(launch_rows_to_tl(g_acts + (size_t)(bi - 3) * total * 128, total, n_tiles, 1, buf[g], st));
     }

@@ -52,13 +52,36 @@ hipError_t launch_pack_bwd_streams(const float* net_keras, float* dst, hipStream
 }
 
 
+// ---- where a workgroup's weight-gradient partial goes ------------------------------------------------------------------
+// Default: fp32 atomics straight onto the gradient (fast, but the order in which the <= 512 workgroups arrive is not
+// fixed, so the last bits of the gradient vary from run to run).  Deterministic mode (mvnerf_set_deterministic): every
+// workgroup STORES its partial of the contiguous span [dW | db] at part + blockIdx.x * part_stride, and
+// reduce_partials_kernel adds the partials onto the gradient in workgroup order.
+__device__ __forceinline__ void grad_out(float* dst, float v, bool store) {
+    if (store) *dst = v;
+    else atomicAdd(dst, v);
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ part, long part_stride, int n_parts, int count, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.0f;
+    for (int w = 0; w < n_parts; ++w) s = s + part[(long)w * part_stride + i];
+    dst[i] = dst[i] + s;
+}
+
+hipError_t launch_reduce_partials(const float* part, long part_stride, int n_parts, int count, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((count + 255) / 256), dim3(256), 0, st, part, part_stride, n_parts, count, dst);
+    return hipGetLastError();
+}
+
 // ---- dW[k][n] += sum_rows relu(a)[k] g[n] ; db[n] += sum_rows g[n] -----------------------------------------
 // a_tl: (rows,128) pre-activations in TL (relu applied on load when relu_a); g_tl: (rows, 32*kNB) in TL.
 // Wave w of a workgroup owns rows k in [32w, 32w+32) of dW and all kNB column blocks.
 template <int kNB>
 __global__ __launch_bounds__(256) void dw_tile_kernel(const float* __restrict__ a_tl, int relu_a, const float* __restrict__ g_tl,
                                                       long n_tiles, float* __restrict__ dW, int ldn, int n_valid,
-                                                      float* __restrict__ db) {
+                                                      float* __restrict__ db, long part_stride) {
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     f32x16 acc[kNB];
@@ -97,30 +120,40 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const float* __restrict__ 
         }
     }
     const int col = lane & 31, hh = lane >> 5;
+    const bool store = part_stride != 0;
+    dW += (long)blockIdx.x * part_stride;
+    if (db) db += (long)blockIdx.x * part_stride;
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) {
         if (32 * nb + col < n_valid) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                atomicAdd(dW + (long)(32 * w + acc_row(r, hh)) * ldn + 32 * nb + col, acc[nb][r]);
+                grad_out(dW + (long)(32 * w + acc_row(r, hh)) * ldn + 32 * nb + col, acc[nb][r], store);
         }
         if (db && w == 0) {
             const float s = dbacc[nb] + __shfl_xor(dbacc[nb], 32);
-            if (hh == 0 && 32 * nb + col < n_valid) atomicAdd(db + 32 * nb + col, s);
+            if (hh == 0 && 32 * nb + col < n_valid) grad_out(db + 32 * nb + col, s, store);
         }
     }
 }
 
+// `part` (deterministic mode, else nullptr): scratch for max_wgs partials of the span [dW | db] (db directly behind dW).
 hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int g_feats, long n_tiles, float* dW, int ldn,
-                          int n_valid, float* db, int max_wgs, hipStream_t st) {
+                          int n_valid, float* db, int max_wgs, float* part, hipStream_t st) {
     const unsigned wgs = (unsigned)(n_tiles < max_wgs ? n_tiles : max_wgs);
+    const int span = 128 * ldn + (db ? (int)(db - dW) - 128 * ldn + n_valid : 0);
+    const long stride = part ? span : 0;
+    float* dWk = part ? part : dW;
+    float* dbk = db ? dWk + (db - dW) : nullptr;
     if (g_feats == 128)
-        hipLaunchKernelGGL(dw_tile_kernel<4>, dim3(wgs), dim3(256), 0, st, a_tl, relu_a, g_tl, n_tiles, dW, ldn, n_valid, db);
+        hipLaunchKernelGGL(dw_tile_kernel<4>, dim3(wgs), dim3(256), 0, st, a_tl, relu_a, g_tl, n_tiles, dWk, ldn, n_valid, dbk, stride);
     else if (g_feats == 32)
-        hipLaunchKernelGGL(dw_tile_kernel<1>, dim3(wgs), dim3(256), 0, st, a_tl, relu_a, g_tl, n_tiles, dW, ldn, n_valid, db);
+        hipLaunchKernelGGL(dw_tile_kernel<1>, dim3(wgs), dim3(256), 0, st, a_tl, relu_a, g_tl, n_tiles, dWk, ldn, n_valid, dbk, stride);
     else
         return hipErrorInvalidValue;
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !part) return e;
+    return launch_reduce_partials(part, stride, (int)wgs, span, dW, st);
 }
 
 // ---- fused backward of one Dense(128 -> 128): dX and dW from ONE pass over the tile ---------------------------
@@ -169,7 +202,7 @@ template <bool kDW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_bwd_fused_kernel(const float* __restrict__ g_tl, const float* __restrict__ a_tl,
                                                                  const float* __restrict__ wstream,
                                                                  const float* __restrict__ resid_tl, float* __restrict__ da_tl,
-                                                                 long n_tiles, float* __restrict__ dW, float* __restrict__ db) {
+                                                                 long n_tiles, float* __restrict__ dW, float* __restrict__ db, long part_stride) {
     __shared__ __attribute__((aligned(16))) f32x4 sG[1024], sA[1024];          // 2 x 16 KiB
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, i = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -336,24 +369,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     if (!kDW) return;                                      // frozen trunk (query_vjp): only dL/da is wanted
     const int col = lane & 31, hh = lane >> 5;
+    const bool store = part_stride != 0;
+    dW += (long)blockIdx.x * part_stride;
+    db += (long)blockIdx.x * part_stride;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(dW + (long)(32 * w + acc_row(r, hh)) * kHidden + 32 * nb + col, dwacc[nb][r]);
+        for (int r = 0; r < 16; ++r) grad_out(dW + (long)(32 * w + acc_row(r, hh)) * kHidden + 32 * nb + col, dwacc[nb][r], store);
         if (w == 0) {
             const float sdb = dbacc[nb] + __shfl_xor(dbacc[nb], 32);
-            if (hh == 0) atomicAdd(db + 32 * nb + col, sdb);
+            if (hh == 0) grad_out(db + 32 * nb + col, sdb, store);
         }
     }
 }
 
 hipError_t launch_dense_bwd_fused(const float* g_tl, const float* a_tl, const float* wstream, const float* resid_tl,
-                                  float* da_tl, long n_tiles, float* dW, float* db, int max_wgs, hipStream_t st) {
-    // (two-stage reduction of the 512 weight-gradient partials instead of the fp32 atomics: measured, no difference)
+                                  float* da_tl, long n_tiles, float* dW, float* db, int max_wgs, float* part, hipStream_t st) {
+    // (two-stage reduction of the 512 weight-gradient partials instead of the fp32 atomics: round 1 measured no difference in
+    // time; `part` != nullptr selects it for run-to-run identical gradients.  db sits directly behind dW: one span.)
     const unsigned wgs = (unsigned)(n_tiles < max_wgs ? n_tiles : max_wgs);
-    if (dW) hipLaunchKernelGGL(dense_bwd_fused_kernel<true>, dim3(wgs), dim3(256), 0, st, g_tl, a_tl, wstream, resid_tl, da_tl, n_tiles, dW, db);
-    else hipLaunchKernelGGL(dense_bwd_fused_kernel<false>, dim3(wgs), dim3(256), 0, st, g_tl, a_tl, wstream, resid_tl, da_tl, n_tiles, dW, db);
-    return hipGetLastError();
+    if (!dW) {
+        hipLaunchKernelGGL(dense_bwd_fused_kernel<false>, dim3(wgs), dim3(256), 0, st, g_tl, a_tl, wstream, resid_tl, da_tl, n_tiles, dW, db, 0L);
+        return hipGetLastError();
+    }
+    if (part && db != dW + kHidden * kHidden) return hipErrorInvalidValue;
+    const int span = kHidden * kHidden + kHidden;
+    hipLaunchKernelGGL(dense_bwd_fused_kernel<true>, dim3(wgs), dim3(256), 0, st, g_tl, a_tl, wstream, resid_tl, da_tl, n_tiles,
+                       part ? part : dW, part ? part + kHidden * kHidden : db, part ? (long)span : 0L);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !part) return e;
+    return launch_reduce_partials(part, span, (int)wgs, span, dW, st);
 }
 
 // ---- loss: d pred = 2 (pred - y) / n ; loss += sum (pred - y)^2 / n   (Keras MeanSquaredError) ----
@@ -695,7 +740,7 @@ struct SampleGeom {       // per sample, in wave-private LDS
 constexpr int kPeRow = 121;           // odd row stride: conflict-free "lane = sample" writes
 
 __global__ __launch_bounds__(256) void dw0_kernel(FieldParams p, const float* __restrict__ g0_tl, float* __restrict__ dW0,
-                                                  float* __restrict__ db0, int y0) {
+                                                  float* __restrict__ db0, int y0, long part_stride) {
     __shared__ SampleGeom geom[4][32];
     extern __shared__ float pe_lds[];                      // 4 x 32 x kPeRow floats for the launch with the PE row blocks
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
@@ -797,21 +842,24 @@ __global__ __launch_bounds__(256) void dw0_kernel(FieldParams p, const float* __
         }
     }
     const int col = lane & 31, hh = lane >> 5;
+    const bool store = part_stride != 0;
+    dW0 += (long)blockIdx.x * part_stride;
+    db0 += (long)blockIdx.x * part_stride;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = 32 * kb + acc_row(r, hh);
-            if (k < kIn) atomicAdd(dW0 + (long)k * kHidden + 32 * nb + col, acc[nb][r]);
+            if (k < kIn) grad_out(dW0 + (long)k * kHidden + 32 * nb + col, acc[nb][r], store);
         }
         if (kb == 0) {
             const float s = dbacc[nb] + __shfl_xor(dbacc[nb], 32);
-            if (hh == 0) atomicAdd(db0 + 32 * nb + col, s);
+            if (hh == 0) grad_out(db0 + 32 * nb + col, s, store);
         }
     }
 }
 
-hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, float* db0, int max_wgs, hipStream_t st) {
+hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, float* db0, int max_wgs, float* part, hipStream_t st) {
     const long view_tiles = p.n_tiles * p.V;
     const unsigned wgs = (unsigned)(view_tiles < max_wgs ? view_tiles : max_wgs);
     // two launches: row blocks 0..3 (PE rows; 62 KiB of PE tables per workgroup) and row blocks 4..11 (feature rows, no
@@ -826,9 +874,16 @@ hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, floa
             return e;
         attr_done[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(dw0_kernel, dim3(wgs, 1), dim3(256), pe_bytes, st, p, g0_tl, dW0, db0, 0);
-    hipLaunchKernelGGL(dw0_kernel, dim3(wgs, 2), dim3(256), 0, st, p, g0_tl, dW0, db0, 1);
-    return hipGetLastError();
+    if (part && db0 != dW0 + kIn * kHidden) return hipErrorInvalidValue;       // one span [dW0 | db0]
+    const int span = kIn * kHidden + kHidden;
+    float* dWk = part ? part : dW0;
+    float* dbk = part ? part + kIn * kHidden : db0;
+    const long stride = part ? span : 0;
+    hipLaunchKernelGGL(dw0_kernel, dim3(wgs, 1), dim3(256), pe_bytes, st, p, g0_tl, dWk, dbk, 0, stride);
+    hipLaunchKernelGGL(dw0_kernel, dim3(wgs, 2), dim3(256), 0, st, p, g0_tl, dWk, dbk, 1, stride);
+    e = hipGetLastError();
+    if (e != hipSuccess || !part) return e;
+    return launch_reduce_partials(part, stride, (int)wgs, span, dW0, st);
 }
 
 // ---- gradient of the field w.r.t. the sample depths (single view) ----------------------------------------------

@@ -184,13 +184,17 @@ class MVVNeRFRenderer:
 
     # ---- training (model_v0.py:186-197, train_nerf.py:20-34, nerf_utils.py:8-12) -----------------------------
     def compile(self, learning_rate=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7, gradients_clip=1.0,
-                train_readout=False, grad_sync=None, encoder_optimizer=None):
+                train_readout=False, grad_sync=None, encoder_optimizer=None, deterministic=None):
         """train_nerf.py:20-34: MSE loss, Adam(1e-4) on the coarse and fine embeddings.
         `learning_rate` may be a callable of the step (e.g. nerf_utils.WarmupScheduler).
         train_readout=False mirrors the reference's MultiOptimizer list, which names only the two embeddings
         (SURVEY.md Q9); set True to update the RenderReadout kernels as well.
         grad_sync: optional callable on the single flat gradient buffer (494 600 fp32), e.g.
-        distributed.allreduce_mean_ for data-parallel training (one collective per step)."""
+        distributed.allreduce_mean_ for data-parallel training (one collective per step).
+        deterministic: True / False sets the library's weight-gradient reduction mode (ops.set_deterministic: fixed-order sums
+        instead of fp32 atomics, bit-identical gradients from run to run); None leaves it as it is."""
+        if deterministic is not None:
+            ops.set_deterministic(deterministic)
         self._opt = dict(lr=learning_rate, b1=beta_1, b2=beta_2, eps=epsilon, clip=gradients_clip, step=0)
         self._grad = torch.zeros(2 * NET_PARAMS, dtype=torch.float32, device=self.device)
         self._adam_m = torch.zeros_like(self._grad)

@@ -538,6 +538,12 @@ def field_backward(rays_o, rays_d, z, images, features, intrinsics, extrinsics_i
     return scratch
 
 
+def set_deterministic(on=True):
+    """mvnerf_set_deterministic: weight gradients summed in a fixed order (bit-identical from run to run) instead of by fp32
+    atomics; returns the previous mode."""
+    return bool(_lib.lib().mvnerf_set_deterministic(int(bool(on))))
+
+
 def adam_clip(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, clip=1.0, update_mask=None):
     """optimize() (nerf_utils.py:8-12): clip-by-value then Adam, in place on `param`, `m`, `v`."""
     _chk(param, 'param')
