@@ -157,3 +157,28 @@ def test_train_step_trains_the_feature_producer_end_to_end():
     m.train_step((inputs, y), u_coarse=dev(sc['u_coarse']), u_fine=dev(sc['u_fine']), stop_fine_z=True)
     assert any(not torch.equal(a, b) for a, b in zip(before, prod.trainable_parameters()))  # ... and is not after the warm-up step
     assert torch.equal(prod.combine_clip_visual.conv.weight, twin.combine_clip_visual.conv.weight.float().to(DEV))  # not in the optimizer list (Q9)
+
+
+def test_device_resident_generator_matches_reference_goldens(golden_dir):
+    """a3 caller side on the GPU: pixel indices from the host RNG, rays from mvnerf_get_rays, targets by a device
+    gather - against what the reference's own generate_rays / get_target produced (tests/golden/datagen.npz)."""
+    import os
+    from thesis_clip_nerf_amd.train_nerf import MVNeRFDataGenerator
+
+    class _OneView:
+        n_perspectives = 1
+
+        def __len__(self):
+            return 1
+    g = np.load(os.path.join(golden_dir, 'datagen.npz'))
+    for i in range(3):
+        gen = MVNeRFDataGenerator(_OneView(), n_rays_train=int(g[f'case{i}_n']), shuffle=False, device=DEV)
+        cam = {'pose': g[f'case{i}_pose'], 'intrinsics': g[f'case{i}_intrinsics']}
+        np.random.seed(int(g[f'case{i}_seed']))
+        r_d, r_o, px = gen.generate_rays_device(g[f'case{i}_color'], cam)
+        np.testing.assert_array_equal(px.cpu().numpy(), g[f'case{i}_rays'])                       # integer (row, col): bit-exact
+        want_d = g[f'case{i}_r_d'].astype(np.float32)                                            # float64 math, float32 storage (Q2)
+        assert np.abs(r_d.cpu().numpy() - want_d).max() <= 6e-8                                  # <= 1 ulp of a unit vector component
+        np.testing.assert_array_equal(r_o.cpu().numpy(), g[f'case{i}_r_o'].astype(np.float32))
+        tgt = gen.get_target_device(dev(g[f'case{i}_color']), px)
+        np.testing.assert_allclose(tgt.cpu().numpy(), g[f'case{i}_target'], rtol=0, atol=6e-8)
