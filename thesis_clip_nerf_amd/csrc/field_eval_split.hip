@@ -183,10 +183,10 @@ __device__ __forceinline__ int ring_start_chunk(int p, int V, int l0_units) {
 // The weight stream reaches LDS through registers: after its first output block a k-step at position p stores what the
 // previous k-step loaded (position p + 2, 12 KiB contiguous in the stream: every thread one dwordx4 + one dwordx2 = 24 B,
 // the same two instructions in every wave, no branch) into slot (c + 2) % 3 and loads position p + 3 into the same
-// registers - a whole k-step of matrix work lies between a load and the store that waits for it.  LDS-DMA (global_load_lds) looked like the natural tool and was the first version, but a CU accepts
-// only about one 1 KiB DMA instruction per ~110 cycles (in-kernel stamps; MI355X_MICROARCH.md quotes 25 GB/s per CU for
-// LDS-DMA fills) - 12 per k-step is 1300 cycles of blocked instruction issue against 1536 cycles of matrix work; the
-// vector-memory path does the same 12 KiB at 64 B/clk.
+// registers - a whole k-step of matrix work lies between a load and the store that waits for it, no counted vmcnt, three
+// slots.  LDS-DMA (global_load_lds_dwordx4 into a 5-slot ring with counted waits) was the first version and measured the
+// same within the box-to-box spread; 12 chunks do not divide evenly over 8 waves there, and the dwordx3
+// form that would writes LDS at a 16-byte lane stride (scripts/dma3_probe.hip).
 __device__ __forceinline__ void ring_store(Ring& r) {
     if (MVS_ABL_NODMA) return;
     int slot = r.c + 2;
