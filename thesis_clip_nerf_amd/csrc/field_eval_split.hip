@@ -135,6 +135,9 @@ __device__ __forceinline__ void split3(const float (&x)[8], u32x4& p1, u32x4& p2
 #ifndef MVS_STAGE_LATE
 #define MVS_STAGE_LATE 1   // 1: a k-step stores (after its first output block) what the PREVIOUS k-step loaded, then loads position p + 3:
 #endif                     //    the loads have a whole k-step to land before anything waits for them; 0: load p + 2, store at the k-step's end
+#ifndef MVS_MV_W4
+#define MVS_MV_W4 0       // multi-view kernels as 4 waves x 512 registers (view sum in registers, no scratch) instead of 8 x 256
+#endif                     // with the view sum spilled: A/B equal (0.47 vs 0.48 of peak at V = 3), 8 x 256 kept
 #ifndef MVS_STAMP
 #define MVS_STAMP 0        // debugging: per-wave cycle totals (k-step bodies / barrier waits / whole kernel) over the `pix` output
 #endif
@@ -158,8 +161,9 @@ struct Ring {
     const int* table;   // LDS: first chunk of every position of one tile
     int start_pf;       // table entry (first chunk) of the position the next ring_fetch loads, read one k-step ahead
     int off_a, off_b;   // this thread's 16 + 8 bytes inside a slot: wave * 1536 + lane * 16 | wave * 1536 + 1024 + lane * 8
-    f32x4 stg0;         // the fetched bytes on their way to LDS
+    f32x4 stg0;         // the fetched bytes on their way to LDS (8 waves: 16 + 8 B per thread; 4 waves: 3 x 16 B)
     f32x2 stg1;
+    f32x4 stg2, stg3;
 #if MVS_STAMP
     unsigned long long t_last, t_body, t_wait, t_grp[4], t_mark;
 #endif
@@ -187,21 +191,41 @@ __device__ __forceinline__ int ring_start_chunk(int p, int V, int l0_units) {
 // slots.  LDS-DMA (global_load_lds_dwordx4 into a 5-slot ring with counted waits) was the first version and measured the
 // same within the box-to-box spread; 12 chunks do not divide evenly over 8 waves there, and the dwordx3
 // form that would writes LDS at a 16-byte lane stride (scripts/dma3_probe.hip).
+// kW = waves of the workgroup: 8 (two 256-register waves per SIMD) or 4 (multi-view kernels: one 512-register wave per SIMD,
+// so that the view sum stays in registers; a thread then moves 3 x 16 B of every slot)
+template <int kW>
 __device__ __forceinline__ void ring_store(Ring& r) {
     if (MVS_ABL_NODMA) return;
     int slot = r.c + 2;
     slot = slot >= kRing ? slot - kRing : slot;
     char* dst = reinterpret_cast<char*>(r.base) + slot * (kSlotF4 * 16);
-    *reinterpret_cast<f32x4*>(dst + r.off_a) = r.stg0;
-    *reinterpret_cast<f32x2*>(dst + r.off_b) = r.stg1;
+    if (kW == 8) {
+        *reinterpret_cast<f32x4*>(dst + r.off_a) = r.stg0;
+        *reinterpret_cast<f32x2*>(dst + r.off_b) = r.stg1;
+    } else {
+        *reinterpret_cast<f32x4*>(dst + r.off_a) = r.stg0;
+        *reinterpret_cast<f32x4*>(dst + r.off_a + 4096) = r.stg2;
+        *reinterpret_cast<f32x4*>(dst + r.off_a + 8192) = r.stg3;
+    }
 }
 
+template <int kW>
+__device__ __forceinline__ void ring_load_stage(Ring& r, const char* src) {
+    if (kW == 8) {
+        r.stg0 = *reinterpret_cast<const f32x4*>(src + r.off_a);
+        r.stg1 = *reinterpret_cast<const f32x2*>(src + r.off_b);
+    } else {
+        r.stg0 = *reinterpret_cast<const f32x4*>(src + r.off_a);
+        r.stg2 = *reinterpret_cast<const f32x4*>(src + r.off_a + 4096);
+        r.stg3 = *reinterpret_cast<const f32x4*>(src + r.off_a + 8192);
+    }
+}
+
+template <int kW>
 __device__ __forceinline__ void ring_fetch(Ring& r) {
     if (MVS_ABL_NODMA) return;
-    if (MVS_STAGE_LATE) ring_store(r);                                  // position p + 2, loaded one k-step ago
-    const char* src = reinterpret_cast<const char*>(r.w) + (long)(MVS_ABL_DMA ? 0 : r.start_pf) * 1024;
-    r.stg0 = *reinterpret_cast<const f32x4*>(src + r.off_a);
-    r.stg1 = *reinterpret_cast<const f32x2*>(src + r.off_b);
+    if (MVS_STAGE_LATE) ring_store<kW>(r);                              // position p + 2, loaded one k-step ago
+    ring_load_stage<kW>(r, reinterpret_cast<const char*>(r.w) + (long)(MVS_ABL_DMA ? 0 : r.start_pf) * 1024);
     int pp = r.p + 3 + MVS_STAGE_LATE;                                  // table entry the NEXT k-step's fetch needs
     pp = pp >= r.P ? pp - r.P : pp;
     r.start_pf = r.table[pp];
@@ -214,12 +238,13 @@ __device__ __forceinline__ const f32x4* ring_nxt(const Ring& r) { return r.base 
 // p - 1, which nobody reads any more since the previous barrier - and the barrier publishes it.  A k-step reads its own slot
 // and, for the A operands of the next k-step's first output block, the next one: both were published at least one barrier
 // ago.
+template <int kW>
 __device__ __forceinline__ void ring_next(Ring& r) {
 #if MVS_STAMP
     const unsigned long long t1 = __builtin_readcyclecounter();
     r.t_body += t1 - r.t_last;
 #endif
-    if (!MVS_STAGE_LATE) ring_store(r);
+    if (!MVS_STAGE_LATE) ring_store<kW>(r);
 #if MVS_ABL_BARRIER
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
@@ -266,7 +291,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], BParts& b) {
 // the MFMAs of output block nb run, the A operands of the next block (of the NEXT k-step's block 0 at nb = 3) are read
 // from LDS and, with kNext, a quarter of the next k-step's B operand is cut on the vector ALU - two vector instructions per
 // MFMA gap, which the matrix pipe hides (MI355X_MICROARCH.md: <= 5 single-issue fillers per 32x32x16 MFMA).
-template <bool kRelu, bool kNext>
+template <bool kRelu, bool kNext, int kW>
 __device__ __forceinline__ void kstep_mfma(Ring& ring, int lane, const BParts& b, const float (&n8)[8], BParts& bn, f32x16 (&acc)[4]) {
     const f32x4* cur = ring_cur(ring) + lane;
     const f32x4* nxt = ring_nxt(ring) + lane;
@@ -304,7 +329,7 @@ __device__ __forceinline__ void kstep_mfma(Ring& ring, int lane, const BParts& b
         }
 #endif
         if (nb + 1 == MVS_DMA_AT) {   // the weight loads of two k-steps ahead
-            ring_fetch(ring);
+            ring_fetch<kW>(ring);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -329,6 +354,7 @@ __device__ __forceinline__ void kstep_mfma(Ring& ring, int lane, const BParts& b
 // acc += W^T relu(in) for one hidden layer: 8 k-steps (input block kb = g / 2, registers 8 (g & 1) .. + 7).  The cut of
 // k-step 0's operand cannot overlap anything of this wave (it needs the previous layer's last MFMA); k-steps 1..7 are cut
 // during the MFMAs of their predecessors.
+template <int kW>
 __device__ __forceinline__ void dense128_split(Ring& ring, int lane, const f32x16 (&in)[4], f32x16 (&acc)[4]) {
     BParts b, bn;
     {
@@ -342,10 +368,10 @@ __device__ __forceinline__ void dense128_split(Ring& ring, int lane, const f32x1
         float n8[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) n8[q] = g < 7 ? in[(g + 1) >> 1][8 * ((g + 1) & 1) + q] : 0.0f;
-        if (g < 7) kstep_mfma<true, true>(ring, lane, b, n8, bn, acc);
-        else kstep_mfma<true, false>(ring, lane, b, n8, bn, acc);
+        if (g < 7) kstep_mfma<true, true, kW>(ring, lane, b, n8, bn, acc);
+        else kstep_mfma<true, false, kW>(ring, lane, b, n8, bn, acc);
         b = bn;
-        ring_next(ring);
+        ring_next<kW>(ring);
     }
 }
 
@@ -385,7 +411,8 @@ constexpr int kStageRowBytes = 256;      // per staged sample row: 64 fp32 chann
 // kProj: layer 0's feature rows come from the fp32 texel table (project_texels_kernel, field_eval.hip).
 // kStash (training forward): the trunk's pre-activations go to HBM in tile layout, as field_eval_kernel<.., kStash> does.
 template <bool kMultiView, bool kProj, bool kStash>
-__global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(FieldParams p, const f32x4* __restrict__ wsplit) {
+__global__ __launch_bounds__((kMultiView && MVS_MV_W4) ? 256 : 512, (kMultiView && MVS_MV_W4) ? 1 : 2) void field_eval_split_kernel(FieldParams p, const f32x4* __restrict__ wsplit) {
+    constexpr int kW = (kMultiView && MVS_MV_W4) ? 4 : 8;                                  // waves per workgroup (see ring_store)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sp[];
     constexpr int kRingBytes = kRing * kSlotF4 * 16;                        // 36 KiB
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
@@ -393,8 +420,8 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
     unsigned char* stage = smem_sp + kRingBytes + wave * (32 * kStageRowBytes);   // 8 KiB per wave
     // all biases (accumulator order) and the read-out bias live in LDS for the whole kernel (a global load in the middle of
     // a k-step would make the in-order vmcnt wait drain the weight prefetch)
-    float* net = reinterpret_cast<float*>(smem_sp + kRingBytes + kWgWaves * 32 * kStageRowBytes) - kPackB0;
-    for (int i = tid; i < kPackBr + 8 - kPackB0; i += 64 * kWgWaves) net[kPackB0 + i] = p.net[kPackB0 + i];
+    float* net = reinterpret_cast<float*>(smem_sp + kRingBytes + kW * 32 * kStageRowBytes) - kPackB0;
+    for (int i = tid; i < kPackBr + 8 - kPackB0; i += 64 * kW) net[kPackB0 + i] = p.net[kPackB0 + i];
 
     Ring ring;
     ring.w = wsplit;
@@ -407,24 +434,22 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
     ring.tid = tid;
     ring.wave = wave;
     {   // chunk every position of a tile starts at
-        int* table = reinterpret_cast<int*>(smem_sp + kRingBytes + kWgWaves * 32 * kStageRowBytes + (kPackBr + 8 - kPackB0) * 4);
-        for (int i = tid; i < ring.P; i += 64 * kWgWaves) table[i] = ring_start_chunk(i, p.V, ring.l0_units);
+        int* table = reinterpret_cast<int*>(smem_sp + kRingBytes + kW * 32 * kStageRowBytes + (kPackBr + 8 - kPackB0) * 4);
+        for (int i = tid; i < ring.P; i += 64 * kW) table[i] = ring_start_chunk(i, p.V, ring.l0_units);
         ring.table = table;
     }
     __syncthreads();                                                        // the position table is written
-    ring.off_a = wave * 1536 + lane * 16;
+    ring.off_a = kW == 8 ? wave * 1536 + lane * 16 : tid * 16;
     ring.off_b = wave * 1536 + 1024 + lane * 8;
     for (int q = 0; q < 2; ++q) {                                           // prologue: positions 0 and 1 into slots 0 and 1
         const char* src = reinterpret_cast<const char*>(wsplit) + (long)ring.table[q] * 1024;
-        char* dst = reinterpret_cast<char*>(ring.base) + q * (kSlotF4 * 16);
-        *reinterpret_cast<f32x4*>(dst + ring.off_a) = *reinterpret_cast<const f32x4*>(src + ring.off_a);
-        *reinterpret_cast<f32x2*>(dst + ring.off_b) = *reinterpret_cast<const f32x2*>(src + ring.off_b);
+        ring_load_stage<kW>(ring, src);
+        ring.c = q == 0 ? 1 : 2;                                            // ring_store writes slot (c + 2) % 3
+        ring_store<kW>(ring);
+
     }
-    if (MVS_STAGE_LATE) {
-        const char* src = reinterpret_cast<const char*>(wsplit) + (long)ring.table[2] * 1024;
-        ring.stg0 = *reinterpret_cast<const f32x4*>(src + ring.off_a);
-        ring.stg1 = *reinterpret_cast<const f32x2*>(src + ring.off_b);
-    }
+    ring.c = 0;
+    if (MVS_STAGE_LATE) ring_load_stage<kW>(ring, reinterpret_cast<const char*>(wsplit) + (long)ring.table[2] * 1024);
     ring.start_pf = ring.table[2 + MVS_STAGE_LATE];
     __syncthreads();
 #pragma unroll
@@ -438,9 +463,9 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
     for (int q = 0; q < 4; ++q) ring.t_grp[q] = 0;
 #endif
 
-    const long n_groups = (p.n_tiles + kWgWaves - 1) / kWgWaves;
+    const long n_groups = (p.n_tiles + kW - 1) / kW;
     for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        long tile = grp * kWgWaves + wave;
+        long tile = grp * kW + wave;
         const bool tile_ok = tile < p.n_tiles;
         if (!tile_ok) tile = p.n_tiles - 1;                               // idle waves shadow the last tile, no stores
         long g = tile * 32 + j;
@@ -534,10 +559,10 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
                     float n8[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) n8[q] = ks < 3 ? pe[8 * (ks + 1) + q] : 0.0f;
-                    if (ks < 3) kstep_mfma<false, true>(ring, lane, bq, n8, bqn, x);
-                    else kstep_mfma<false, false>(ring, lane, bq, n8, bqn, x);
+                    if (ks < 3) kstep_mfma<false, true, kW>(ring, lane, bq, n8, bqn, x);
+                    else kstep_mfma<false, false, kW>(ring, lane, bq, n8, bqn, x);
                     bq = bqn;
-                    ring_next(ring);
+                    ring_next<kW>(ring);
                 }
             }
 
@@ -600,8 +625,8 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
                         const float b8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                         BParts bq, bqn;
                         split8<false>(b8, bq);
-                        kstep_mfma<false, false>(ring, lane, bq, b8, bqn, x);
-                        ring_next(ring);
+                        kstep_mfma<false, false, kW>(ring, lane, bq, b8, bqn, x);
+                        ring_next<kW>(ring);
                     }
                 }
             }
@@ -616,10 +641,10 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
             for (int bi = 0; bi < 3; ++bi) {
                 const float* bias1 = net + kPackBHidden + 256 * bi;
                 bias_acc<false>(bias1, h, hid);
-                dense128_split(ring, lane, x, hid);
+                dense128_split<kW>(ring, lane, x, hid);
                 if (kStash && tile_ok) store_tl(p.stash + (1 + 2 * bi) * p.stash_stride, vtile, j, h, hid);
                 bias_acc<true>(bias1 + 128, h, x);
-                dense128_split(ring, lane, hid, x);
+                dense128_split<kW>(ring, lane, hid, x);
                 if (kStash && tile_ok) store_tl(p.stash + (2 + 2 * bi) * p.stash_stride, vtile, j, h, x);
                 if (p.acts_view && valid) store_row(p.acts_view + (bi + 1) * vslot + 128 * vrow);
             }
@@ -641,10 +666,10 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
         for (int bi = 3; bi < 6; ++bi) {
             const float* bias1 = net + kPackBHidden + 256 * bi;
             bias_acc<false>(bias1, h, hid);
-            dense128_split(ring, lane, x, hid);
+            dense128_split<kW>(ring, lane, x, hid);
             if (kStash && tile_ok) store_tl(p.stash_fused + (1 + 2 * (bi - 3)) * p.stash_fused_stride, tile, j, h, hid);
             bias_acc<true>(bias1 + 128, h, x);
-            dense128_split(ring, lane, hid, x);
+            dense128_split<kW>(ring, lane, hid, x);
             if (kStash && tile_ok) store_tl(p.stash_fused + (2 + 2 * (bi - 3)) * p.stash_fused_stride, tile, j, h, x);
             if (p.acts_fused && valid) store_row(p.acts_fused + (long)(bi - 2) * p.total * 128 + 128 * g);
         }
@@ -683,19 +708,19 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_split_kernel(Fiel
                 out[3] = softplus_f32(o[3]);
                 *reinterpret_cast<f32x4*>(p.rgbs + 4 * g) = out;
             }
-            ring_fetch(ring);
+            ring_fetch<kW>(ring);
             // the next position's first A operands (the invariant every k-step leaves behind)
             {
                 const f32x4* nx = ring_nxt(ring) + lane;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) ring.a0[q] = __builtin_bit_cast(u32x4, nx[q * 64]);
             }
-            ring_next(ring);
+            ring_next<kW>(ring);
         }
     }
 #if MVS_STAMP
     if (lane == 0 && p.pix) {
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.pix) + 8 * (blockIdx.x * kWgWaves + wave);
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.pix) + 8 * (blockIdx.x * kW + wave);
         dbg[0] = ring.t_body;
         dbg[1] = ring.t_wait;
         dbg[2] = __builtin_readcyclecounter() - t_begin;
@@ -725,7 +750,7 @@ hipError_t launch_field_eval_split(const FieldParams& p, const void* packed_spli
     if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
     const int n_pos = ((p.texel_table ? 4 : kSpL0Steps) + kHiddenUnits) * p.V + kHiddenUnits + 2;
     if (n_pos > kMaxPositions) return hipErrorInvalidValue;                  // V <= 14 (direct) / 18 (texel table)
-    const int lds_bytes = kRing * kSlotF4 * 16 + kWgWaves * 32 * kStageRowBytes + (kPackBr + 8 - kPackB0) * 4 + kMaxPositions * 4;
+    const int lds_bytes = kRing * kSlotF4 * 16 + kWgWaves * 32 * kStageRowBytes + (kPackBr + 8 - kPackB0) * 4 + kMaxPositions * 4;   // sized for 8 waves
     {
         std::lock_guard<std::mutex> lock(mtx);
         if (!attr_done[dev]) {
@@ -746,14 +771,16 @@ hipError_t launch_field_eval_split(const FieldParams& p, const void* packed_spli
         }
     }
     if ((e = launch_dir_bias(p, stream)) != hipSuccess) return e;
-    const long n_groups = (p.n_tiles + kWgWaves - 1) / kWgWaves;
+    const bool mv = p.V > 1;
+    const int waves = (mv && MVS_MV_W4) ? 4 : kWgWaves;
+    const long n_groups = (p.n_tiles + waves - 1) / waves;
     const long resident = (long)cus[dev];                                   // persistent: one workgroup per CU
     const unsigned wgs = (unsigned)(n_groups < resident ? n_groups : resident);
     const f32x4* w = static_cast<const f32x4*>(packed_split);
     if (p.stash && p.V > 1 && ((long)p.R * p.S) % 32 != 0) return hipErrorInvalidValue;     // tiles must not straddle scenes
-    const dim3 grid(wgs), block(64 * kWgWaves);
+    const dim3 grid(wgs), block(64 * waves);
 #define MVS_LAUNCH(MV, PROJ, STASH) hipLaunchKernelGGL((field_eval_split_kernel<MV, PROJ, STASH>), grid, block, lds_bytes, stream, p, w)
-    const int variant = (p.V > 1 ? 4 : 0) + (p.texel_table ? 2 : 0) + (p.stash ? 1 : 0);
+    const int variant = (mv ? 4 : 0) + (p.texel_table ? 2 : 0) + (p.stash ? 1 : 0);
     switch (variant) {
         case 0: MVS_LAUNCH(false, false, false); break;
         case 1: MVS_LAUNCH(false, false, true); break;
