@@ -89,3 +89,21 @@ def test_sharded_render_equals_unsharded_bit_for_bit(ranks):
     for rk in ranks:
         for got, want in zip(rk['sharded'], whole):
             assert torch.equal(got, want[0].cpu())
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher in the environment (the driver's command shape): the parent starts the two
+    ranks itself (here on one GPU through gloo), relays ONE JSON line, and the data-parallel training leg leaves both ranks with
+    identical weights."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(MVNERF_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--train-steps', '1'],
+                          env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0 and d['metric'].startswith('rendered rays/sec')
+    assert d['train_cfg4']['weights_identical_across_ranks'] is True and d['train_cfg4']['allreduce_ms'] > 0
+    assert 'cpu_baseline' not in d                                     # rank 0 at N = 1 only

@@ -32,6 +32,7 @@ class TrunkState:
     def __init__(self, images, features, intrinsics, extrinsics_inv, net_keras):
         self.geo = (images.contiguous(), features.contiguous(), intrinsics.contiguous(), extrinsics_inv.contiguous())
         self.packed = ops.pack_net(net_keras)
+        self.packed_split = ops.pack_net_split(net_keras)          # value pass on the split-bf16 kernel (fp32-grade)
         self.bwd_streams = ops.pack_bwd_streams(net_keras)
         self.n_views = images.shape[1]
 
@@ -66,7 +67,7 @@ class TrunkField(torch.autograd.Function):
         b, n, _ = points.shape
         pad = (-n) % 32 if state.n_views > 1 else 0     # the multi-view training kernels want whole 32-point tiles per scene
         p, d = _pad32(points.detach().contiguous(), pad), _pad32(dirs.detach().contiguous(), pad)
-        stash = ops.query_stash(p, d, *state.geo, state.packed)
+        stash = ops.query_stash(p, d, *state.geo, state.packed, packed_split=state.packed_split)
         rows = b * (n + pad)
         tiles = (rows + 31) // 32
         fused = stash.view(torch.float32)[7 * state.n_views * tiles * 4096:][:7 * tiles * 4096].view(7, tiles, 128, 32)

@@ -751,10 +751,11 @@ def query_jvp(points, dirs, t_points, t_dirs, images, features, intrinsics, extr
     return (t_acts, acts) if return_primal else t_acts
 
 
-def query_stash(points, dirs, images, features, intrinsics, extrinsics_inv, packed_net, stash=None):
-    """Forward of the trunk on query points with the pre-activations kept for query_vjp (field_eval_stash, S = 1, z = 0)."""
+def query_stash(points, dirs, images, features, intrinsics, extrinsics_inv, packed_net, stash=None, packed_split=None):
+    """Forward of the trunk on query points with the pre-activations kept for query_vjp (field_eval_stash, S = 1, z = 0);
+    packed_split: run it on the split-bf16 kernel."""
     z = torch.zeros(tuple(points.shape[:2]) + (1,), dtype=torch.float32, device=points.device)
-    return field_eval_stash(points, dirs, z, images, features, intrinsics, extrinsics_inv, packed_net, stash)[1]
+    return field_eval_stash(points, dirs, z, images, features, intrinsics, extrinsics_inv, packed_net, stash, packed_split=packed_split)[1]
 
 
 def query_vjp(points, dirs, images, features, intrinsics, extrinsics_inv, bwd_streams, stash, g_acts):
