@@ -133,7 +133,8 @@ class MVNeRFDataGenerator:
     @staticmethod
     def get_target_device(color_u8, px):
         """get_target (mvnerf.py:45-48) as a device gather: color_u8 (H,W,3) uint8, px (n,2) (row, col)."""
-        return color_u8[px[:, 0], px[:, 1], :3].to(torch.float32) / 255.0
+        # float64 division, then float32: the reference divides in NumPy float64 and Keras casts the labels (bit-identical)
+        return (color_u8[px[:, 0], px[:, 1], :3].to(torch.float64) / 255.0).to(torch.float32)
 
     def get_data_device(self, batch):
         """get_data with the batch assembled on the GPU; consumes the NumPy RNG exactly like get_data."""
