@@ -1,9 +1,8 @@
 // Backward pass of the render path (MVVNeRFRenderer.train_step, model_v0.py:186-197) for gfx950.
 //
-// Layer-major: the forward pass (field_eval_kernel<.., kStash=true>) leaves the 13 pre-activation tensors
-// of the trunk in HBM in tile layout (mvnerf_mfma.h); each Dense layer's backward is then two MFMA kernels
-// over all 32-sample tiles:
-// over all 32-sample tiles, fused in dense_bwd_fused_kernel:
+// Layer-major: the forward pass (field_eval_split_kernel<.., kStash=true>) leaves the 13 pre-activation tensors
+// of the trunk in HBM in tile layout (mvnerf_mfma.h); each Dense layer's backward is then one pass
+// over all 32-sample tiles, dense_bwd_split8_kernel:
 //   dX = (W . G) (.) [pre > 0] (+ residual)   -- the forward's weight-stream MFMA code fed with transposed kernels
 //   dW += relu(pre) . G^T, db += sum G        -- samples are the MFMA K dimension; a workgroup keeps its
 //                                                128x128 partial in registers over its tiles and adds it once
@@ -156,19 +155,24 @@ hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int 
     return launch_reduce_partials(part, stride, (int)wgs, span, dW, st);
 }
 
-// ---- fused backward of one Dense(128 -> 128): dX and dW from ONE pass over the tile ---------------------------
+// ---- backward of one Dense(128 -> 128) over 32-sample tiles ----------------------------------------------------------------
 //   y = W^T relu(a) + b        G = dL/dy (TL),  a = pre-activation input (TL)
 //   dL/da = (W . G) (.) [a > 0] (+ resid)      dW += relu(a) . G^T      db += sum G
-// A workgroup (4 waves) stages the G and a tiles once in LDS (coalesced 16-byte loads, XOR-swizzled so that both
-// the "lane = sample" dword reads and the "lane = feature" 16-byte reads are conflict-free or 2-way) and splits
-// the work by 32-row block: wave w produces rows [32w, 32w+32) of dL/da (64 MFMAs, its quarter of the transposed
-// weight stream) and rows [32w, 32w+32) of dW (64 MFMAs, samples as K), accumulating dW in registers over all the
-// workgroup's tiles and adding it once at the end.
+// Two kernels: dense_dx_kernel (frozen trunk, query_vjp: dL/da only, fp32 MFMA) and dense_bwd_split8_kernel (training: dL/da, dW
+// and db from one pass over the tile, both GEMMs on the bf16 matrix pipe with exactly cut operands).  Both bring the G and a tiles
+// into LDS by LDS-DMA (global_load_lds_dwordx4) with the float4 chunks of a row XOR-swizzled on the SOURCE side, so that the
+// "lane = sample" dword reads and the "lane = feature" 16-byte reads of the image are conflict-free.
+//
+// What round 2 measured on the way (scripts/bwd_probe.hip, scripts/filler_probe.hip, profiles/r02_bwd_*.log):
+//  * the first form kept the next tile in registers while streaming its weight quarter from L2 inside the tile: vmcnt retires in
+//    order, so the first weight wait of a tile also waited for the HBM prefetch issued just before it (340 us per 16384-tile launch);
+//  * weights resident in registers + tiles by LDS-DMA: 300 us; of a tile's 16.7 k cycles per wave 11 k were the MFMA section of
+//    5632 matrix cycles shared by the two waves of a SIMD, and vector instructions do not issue behind a wave's OWN
+//    v_mfma_f32_32x32x2_f32 (4 independent v_add_f32 behind one: 64 -> 94 cycles; behind v_mfma_f32_32x32x16_bf16 five are free),
+//    so the operand cuts of the bf16 weight-gradient GEMM were paid in full;
+//  * the epilogue's stores through a pointer that had passed an inline-asm constraint were FLAT stores (they count in lgkmcnt,
+//    so every LDS read behind one waited for it): 3000 -> 1200 cycles per tile once they are address_space(1) stores.
 __device__ __forceinline__ int swz_f4(int f, int chunk) { return f * 8 + (chunk ^ (f & 7)); }     // float4 index
-
-#ifndef MVT_SPLIT_DW
-#define MVT_SPLIT_DW 1     // weight-gradient GEMM (samples are K) as six bf16 MFMAs per product on exactly cut operands
-#endif                     // (fp32-grade, see field_eval_split.hip) instead of v_mfma_f32_32x32x2_f32: 48 x 32 instead of 64 x 64 matrix cycles per tile
 
 using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4_t = __attribute__((ext_vector_type(4))) unsigned int;
@@ -198,207 +202,436 @@ __device__ __forceinline__ void cut3(const f32x4& lo, const f32x4& hi, u32x4_t& 
     }
 }
 
-template <bool kDW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_bwd_fused_kernel(const float* __restrict__ g_tl, const float* __restrict__ a_tl,
-                                                                 const float* __restrict__ wstream,
-                                                                 const float* __restrict__ resid_tl, float* __restrict__ da_tl,
-                                                                 long n_tiles, float* __restrict__ dW, float* __restrict__ db, long part_stride) {
-    __shared__ __attribute__((aligned(16))) f32x4 sG[1024], sA[1024];          // 2 x 16 KiB
-    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, i = lane & 31;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    f32x16 dwacc[4];
-    float dbacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dwacc[nb][r] = 0.0f;
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wstream), 0, kHiddenWFloats * 4, 0x00020000);
-    const int wvoff = lane * 16 + 1024 * w;               // chunk (grp, nb = w) of every 4 KiB group
+#ifndef MVT_STAMP
+#define MVT_STAMP 0        // scripts/bwd_probe.hip: per-wave cycle totals of the phases of a tile (dense_bwd_split8_kernel)
+#endif
+#if MVT_STAMP
+__device__ unsigned long long g_bwd_stamp[256 * 8 * 8];
+#define STAMP(k) { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[k] += t_ - st_last; st_last = t_; }
+#else
+#define STAMP(k)
+#endif
 
-    // LDS addresses as (4 lane-dependent bases) + compile-time offsets, so that they ride in the ds_read immediates
-    // instead of one address register per row (the XOR term of swz_f4 only sees the low 3 bits of the row):
-    int gbase[4], ebase[4], tbase[4];
+// ---- dL/da only (frozen trunk): a wave's quarter of the transposed weight stream stays in 64 registers for the whole launch, the
+// only vector-memory traffic inside the tile loop is the DMA of the NEXT tile into the other LDS buffer, the residual rows (wave-
+// private, read in the epilogue) and the stores; one workgroup barrier per tile.  4 waves, wave w owns rows [32w, 32w+32).
+constexpr int kBwdBufF4 = 2048;                              // one staged tile pair: G (1024 float4) then a (1024 float4)
+constexpr int kBwdLdsBytes = (2 * kBwdBufF4 + 1024) * 16;    // two buffers + the residual tile: 80 KiB, two workgroups fill a CU's 160 KiB
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_dx_kernel(
+    const float* __restrict__ g_tl, const float* __restrict__ a_tl, const float* __restrict__ wstream, const float* __restrict__ resid_tl,
+    float* __restrict__ da_tl, long n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 sbuf[];
+    using gptr = const __attribute__((address_space(1))) void*;
+    using lptr = __attribute__((address_space(3))) void*;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    f32x4 wreg[16];                                          // chunk (grp, nb = w) of every 4 KiB group of the stream
+    {
+        const f32x4* ws = reinterpret_cast<const f32x4*>(wstream) + 64 * w + lane;
+#pragma unroll
+        for (int grp = 0; grp < 16; ++grp) wreg[grp] = ws[256 * grp];
+    }
+    // lane-dependent LDS float indices, buffer offset included (toggled by XOR at the end of a tile); everything else rides in the
+    // ds_read immediates: G[row 4h+e (+8m)][sample j] and a[row 32w + 4h + e (+8m)][sample j]
+    int gidx[4], eidx[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        gbase[e] = swz_f4(4 * h + e, j >> 2) * 4 + (j & 3);                 // float index of G[row 4h+e (+8m)][sample j]
-        ebase[e] = swz_f4(32 * w + 4 * h + e, j >> 2) * 4 + (j & 3);        // a[row 32w + 4h + e (+8m)][sample j]
-        tbase[e] = swz_f4(i, 2 * e + h);                                    // float4 index of row i (+32m), samples 8e+4h..+3
+        gidx[e] = swz_f4(4 * h + e, j >> 2) * 4 + (j & 3);
+        eidx[e] = 4096 + swz_f4(32 * w + 4 * h + e, j >> 2) * 4 + (j & 3);
     }
-    // software pipeline over the workgroup's tiles: the next tile's G and a (32 KiB) are in flight, in registers,
-    // while the current one is consumed from LDS
-    f32x4 pg[4], pa[4];
-    {
-        const long t0 = blockIdx.x < n_tiles ? (long)blockIdx.x : n_tiles - 1;
-        const f32x4* gsrc = reinterpret_cast<const f32x4*>(g_tl + t0 * 4096);
-        const f32x4* asrc = reinterpret_cast<const f32x4*>(a_tl + t0 * 4096);
+    // DMA: wave-instruction m of wave w fills LDS float4 slots 256m + 64w + lane = (row 32m + 8w + lane/8, physical chunk lane%8),
+    // which holds logical chunk (lane%8) ^ (row%8) = (lane%8) ^ (lane/8) of that row.  Global addresses are a uniform base pinned
+    // to scalar registers plus ONE 32-bit lane offset; the other lane offsets are recomputed from it behind an empty asm (the
+    // compiler would otherwise hoist 64-bit per-lane pointers into registers it has to spill).
+    const unsigned src_off = (unsigned)((lane & 56) + ((lane & 7) ^ (lane >> 3))) * 16u;
+    auto sbase = [](const float* p, long byte_off) {
+        const char* b = reinterpret_cast<const char*>(p) + byte_off;
+        asm volatile("" : "+s"(b));
+        return b;
+    };
+    const int n_tiles32 = (int)n_tiles, stride = (int)gridDim.x;            // tile indices are 32-bit (scalar compares); byte offsets 64-bit
+    auto dma_tile = [&](int t, int buf) {
+        unsigned so = src_off;
+        asm volatile("" : "+v"(so));
+        f32x4* dst = sbuf + buf * kBwdBufF4 + 64 * w;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            pg[m] = gsrc[tid + 256 * m];
-            pa[m] = asrc[tid + 256 * m];
+            __builtin_amdgcn_global_load_lds((gptr)(sbase(g_tl, (long)t * 16384 + 4096 * m + 1024 * w) + so), (lptr)(dst + 256 * m), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(sbase(a_tl, (long)t * 16384 + 4096 * m + 1024 * w) + so), (lptr)(dst + 1024 + 256 * m), 16, 0, 0);
         }
-    }
-    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        __syncthreads();                                   // previous tile fully consumed
+    };
+    auto lane_of = [&]() {                                  // lane id back from src_off
+        unsigned so = src_off;
+        asm volatile("" : "+v"(so));
+        const unsigned x = so >> 4;
+        return (x & 56u) | ((x & 7u) ^ (x >> 3));
+    };
+    dma_tile((int)blockIdx.x, 0);
+    if (!resid_tl) {                                        // no skip gradient: the residual image stays zero
+        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int q = tid + 256 * m;
-            const int dst = swz_f4(q >> 3, q & 7);
-            sG[dst] = pg[m];
-            sA[dst] = pa[m];
-        }
+        for (int m = 0; m < 4; ++m) sbuf[2 * kBwdBufF4 + 256 * w + 64 * m + lane] = z;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    int cur = 0;
+    const float* sF = reinterpret_cast<const float*>(sbuf);
+    for (int tile = (int)blockIdx.x; tile < n_tiles32; tile += stride) {
+        // every wave has its part of this tile in LDS (waited below / above) and is done reading the other buffer
+        asm volatile("s_barrier" ::: "memory");
         {
-            const long nt = tile + gridDim.x < n_tiles ? tile + gridDim.x : tile;
-            const f32x4* gsrc = reinterpret_cast<const f32x4*>(g_tl + nt * 4096);
-            const f32x4* asrc = reinterpret_cast<const f32x4*>(a_tl + nt * 4096);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                pg[m] = gsrc[tid + 256 * m];
-                pa[m] = asrc[tid + 256 * m];
-            }
+            const int nt = tile + stride < n_tiles32 ? tile + stride : tile;
+            dma_tile(nt, cur ^ 1);
         }
-        __syncthreads();
-        // the residual rows of this wave's output block are requested now and consumed in the epilogue: asked for there
-        // (behind the scheduling fences of the MFMA sections) their latency would be exposed once per tile
-        float rs[16];
-        const long obase = tl_index(tile, 128, 32 * w + 4 * h, j);           // row 32w + 4h (+ (r&3) + 8(r>>2))
         if (resid_tl) {
+            const unsigned res_off = lane_of() * 16u;
+            f32x4* rdst = sbuf + 2 * kBwdBufF4 + 256 * w;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rs[r] = resid_tl[obase + ((r & 3) + 8 * (r >> 2)) * 32];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rs[r] = 0.0f;
+            for (int m = 0; m < 4; ++m)
+                __builtin_amdgcn_global_load_lds((gptr)(sbase(resid_tl, (long)tile * 16384 + 4096 * w + 1024 * m) + res_off), (lptr)(rdst + 64 * m), 16, 0, 0);
         }
-        // ---- dL/da rows of block w: out[32w + i'][j] = sum_n M[n][32w + i'] G[n][j]
-        //      and dW rows of block w: dW[32w + i][n] += sum_j relu(a)[32w + i][j] G[n][j], interleaved group by group:
-        //      the two MFMA chains are independent, so each covers the operand latency of the other ----
+        // rows of block w: out[32w + i'][j] = sum_n M[n][32w + i'] G[n][j]; contraction index n = 32kb + 8t + 4h + e of group 4kb + t
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        f32x4 wcur = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, 0, 0));
-        f32x4 wnxt = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, 4096, 0));
-        const float* sGf = reinterpret_cast<const float*>(sG);
         float gcur[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) gcur[e] = sGf[gbase[e]];
-#if !MVT_SPLIT_DW
-        f32x4 a4[4];
-#endif
-        f32x4 dgcur = sG[tbase[0]];
-#if MVT_SPLIT_DW
-        // dW rows of block w on the bf16 matrix pipe: K = the tile's 32 samples = 2 k-steps of 16; lane (i, h) supplies samples
-        // 16 ks + 8 h + {0..7} of row 32 w + i of relu(a) (A operand) and of row 32 nb + i of G (B operand): two float4 chunks
-        // of the staged rows each, cut into three bf16 pieces
-        u32x4_t ap[3], bp[3];
-#else
-        if (kDW) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a4[t] = sA[tbase[t] + 256 * w];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a4[t][e] = fmaxf(a4[t][e], 0.0f);
-            }
-        }
-#endif
-        float sgsum = 0.0f;
+        for (int e = 0; e < 4; ++e) gcur[e] = sF[gidx[e]];
 #pragma unroll
         for (int grp = 0; grp < 16; ++grp) {
-            // operands of the next group (weights from L2, G from LDS in both layouts) are requested before this group's MFMAs
-            // (the weights, an L2 round trip, two groups ahead; past the end of the stream the buffer range check returns 0)
-            const f32x4 wnext2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, 4096 * (grp + 2), 0));
             float gnext[4];
             const int gn = grp < 15 ? grp + 1 : grp;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)                                          // contraction index n = 32kb + 8t + 4h + e
-                gnext[e] = sGf[gbase[e] + (32 * (gn >> 2) + 8 * (gn & 3)) * 32];
-            f32x4 dgnext = dgcur;
-#if MVT_SPLIT_DW
-            if (kDW && (grp & 7) == 0) {                                         // A pieces of k-step ks = grp / 8
-                const int ks = grp >> 3, row = 32 * w + i;
-                cut3<true>(sA[swz_f4(row, 4 * ks + 2 * h)], sA[swz_f4(row, 4 * ks + 2 * h + 1)], ap[0], ap[1], ap[2]);
-            }
-            if (kDW && (grp & 1) == 0) {                                         // pair q = grp / 2 -> (k-step ks = q / 4, output block nb = q % 4)
-                const int q = grp >> 1, row = 32 * (q & 3) + i, ks = q >> 2;
-                const f32x4 g_lo = sG[swz_f4(row, 4 * ks + 2 * h)], g_hi = sG[swz_f4(row, 4 * ks + 2 * h + 1)];
-                cut3<false>(g_lo, g_hi, bp[0], bp[1], bp[2]);
-                dbacc[q & 3] = dbacc[q & 3] + (((g_lo[0] + g_lo[1]) + (g_lo[2] + g_lo[3])) + ((g_hi[0] + g_hi[1]) + (g_hi[2] + g_hi[3])));
-            }
+            for (int e = 0; e < 4; ++e) gnext[e] = sF[gidx[e] + (32 * (gn >> 2) + 8 * (gn & 3)) * 32];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = mfma(wcur[e], gcur[e], acc);
-            if (kDW && (grp & 1) == 1) {
-                const int nb = (grp >> 1) & 3;
-                dwacc[nb] = mfma16s(ap[2], bp[0], dwacc[nb]);
-                dwacc[nb] = mfma16s(ap[1], bp[1], dwacc[nb]);
-                dwacc[nb] = mfma16s(ap[0], bp[2], dwacc[nb]);
-                dwacc[nb] = mfma16s(ap[1], bp[0], dwacc[nb]);
-                dwacc[nb] = mfma16s(ap[0], bp[1], dwacc[nb]);
-                dwacc[nb] = mfma16s(ap[0], bp[0], dwacc[nb]);
-            }
-#else
-            if (kDW) dgnext = sG[tbase[gn & 3] + 256 * (gn >> 2)];               // dW group = (output block nb = grp / 4, t = grp % 4)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc = mfma(wcur[e], gcur[e], acc);
-                if (kDW) {
-                    dwacc[grp >> 2] = mfma(a4[grp & 3][e], dgcur[e], dwacc[grp >> 2]);
-                    sgsum = sgsum + dgcur[e];
-                }
-            }
-#endif
-#if !MVT_SPLIT_DW
-            if (kDW && (grp & 3) == 3) {
-                dbacc[grp >> 2] = dbacc[grp >> 2] + sgsum;
-                sgsum = 0.0f;
-            }
-#endif
-            wcur = wnxt;
-            wnxt = wnext2;
-            dgcur = dgnext;
+            for (int e = 0; e < 4; ++e) acc = mfma(wreg[grp][e], gcur[e], acc);
 #pragma unroll
             for (int e = 0; e < 4; ++e) gcur[e] = gnext[e];
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- epilogue of dL/da: relu mask from the staged a tile, optional residual, store ----
+        // the residual rows and the next tile have landed (they had the whole MFMA section); the previous tile's stores too
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- epilogue: relu mask from the staged a tile, residual, store (address_space(1): see the header) ----
+        const unsigned ln = lane_of();
+        const unsigned oo = ((ln >> 5) * 128u + (ln & 31u)) * 4u;                 // ((4h) * 32 + j) floats
+        const float* sR = sF + 4 * 2 * kBwdBufF4 + 32 * w * 32 + (oo >> 2);
+        char* optr = const_cast<char*>(sbase(da_tl, (long)tile * 16384 + 4096 * w));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float av = reinterpret_cast<const float*>(sA)[ebase[r & 3] + 8 * (r >> 2) * 32];
+            const int ro = ((r & 3) + 8 * (r >> 2)) * 32;
+            const float av = sF[eidx[r & 3] + 8 * (r >> 2) * 32];
             const float v = av > 0.0f ? acc[r] : 0.0f;
-            da_tl[obase + ((r & 3) + 8 * (r >> 2)) * 32] = resid_tl ? v + rs[r] : v;
+            *(__attribute__((address_space(1))) float*)(optr + 4 * ro + oo) = v + sR[ro];
+        }
+        cur ^= 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gidx[e] ^= 4 * kBwdBufF4;
+            eidx[e] ^= 4 * kBwdBufF4;
         }
     }
-    if (!kDW) return;                                      // frozen trunk (query_vjp): only dL/da is wanted
-    const int col = lane & 31, hh = lane >> 5;
-    const bool store = part_stride != 0;
-    dW += (long)blockIdx.x * part_stride;
-    db += (long)blockIdx.x * part_stride;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped re-load of the last tile must land before the LDS is released
+}
+
+// ---- the training form: both GEMMs of the layer backward on the bf16 matrix pipe, roles split over 8 waves --------------------
+//   * dL/da and dW both run as six bf16 MFMAs per product on exactly cut operands (fp32-grade, see field_eval_split.hip):
+//     2 x 48 x 32 matrix cycles per tile instead of 2 x 64 x 64 on the fp32 MFMA;
+//   * G is cut ONCE per tile by the 8 waves together, into two LDS images of bf16 pieces in MFMA-operand order: packed along
+//     the samples (B operand of the weight gradient, K = samples) and packed along the features (B operand of dL/da, K = n);
+//   * waves 0-3 ("Z") own one 32-row block of dL/da each and keep their quarter of W as 3 x 8 x 4 piece registers for the whole
+//     launch; waves 4-7 ("W") own 32 rows of dW each (64 accumulator registers); one workgroup per CU, one Z and one W wave per SIMD.
+// Per tile: barrier (raw tile landed by LDS-DMA) - cut - barrier - MFMA sections - epilogue (Z) / next A cut (W).
+constexpr int kBwd8Raw = 2048, kBwd8Resid = 2 * kBwd8Raw, kBwd8Prow = kBwd8Resid + 1024, kBwd8Pcol = kBwd8Prow + 1536;   // float4 units
+constexpr int kBwd8LdsBytes = (kBwd8Pcol + 1536) * 16;                                                            // 128 KiB
+
+__global__ __launch_bounds__(512, 1) void dense_bwd_split8_kernel(
+    const float* __restrict__ g_tl, const float* __restrict__ a_tl, const float* __restrict__ wstream, const float* __restrict__ resid_tl,
+    float* __restrict__ da_tl, long n_tiles, float* __restrict__ dW, float* __restrict__ db, long part_stride) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 sbuf[];
+    using gptr = const __attribute__((address_space(1))) void*;
+    using lptr = __attribute__((address_space(3))) void*;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, i = lane & 31;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);                  // wave 0..7
+    const float* sF = reinterpret_cast<const float*>(sbuf);
+    u32x4_t* sP = reinterpret_cast<u32x4_t*>(sbuf);
+    const int n_tiles32 = (int)n_tiles, stride = (int)gridDim.x;
+    auto sbase = [](const float* p, long byte_off) {                        // uniform address, pinned to scalar registers
+        const char* b = reinterpret_cast<const char*>(p) + byte_off;
+        asm volatile("" : "+s"(b));
+        return b;
+    };
+    // sum of the 8 gradient values a lane holds (bias gradient), as single v_add_f32: left to the compiler these are packed into
+    // v_pk_add_f32 behind a string of register moves
+    auto sum8 = [](const f32x4& lo, const f32x4& hi, float accv) {
+        float s = lo[0];
+        const float t[7] = {lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
+        for (int q = 0; q < 7; ++q) asm("v_add_f32_e32 %0, %1, %2" : "=v"(s) : "v"(s), "v"(t[q]));
+        asm("v_add_f32_e32 %0, %1, %2" : "=v"(accv) : "v"(accv), "v"(s));
+        return accv;
+    };
+    // raw tile by LDS-DMA: wave-instruction I = 4v + m (0..31) fills float4 slots 64 I .. 64 I + 63 of [G | a] (rows 8 I' ..., the
+    // XOR swizzle of swz_f4 applied on the source side): waves 0-3 bring G, waves 4-7 bring a
+    const unsigned src_off = (unsigned)((lane & 56) + ((lane & 7) ^ (lane >> 3))) * 16u;
+    auto dma_raw = [&](int t, int buf) {
+        unsigned so = src_off;
+        asm volatile("" : "+v"(so));
+        const float* src = v < 4 ? g_tl : a_tl;
+        f32x4* dst = sbuf + buf * kBwd8Raw + 256 * v;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) grad_out(dW + (long)(32 * w + acc_row(r, hh)) * kHidden + 32 * nb + col, dwacc[nb][r], store);
-        if (w == 0) {
-            const float sdb = dbacc[nb] + __shfl_xor(dbacc[nb], 32);
-            if (hh == 0) grad_out(db + 32 * nb + col, sdb, store);
+        for (int m = 0; m < 4; ++m)
+            __builtin_amdgcn_global_load_lds((gptr)(sbase(src, (long)t * 16384 + 4096 * (v & 3) + 1024 * m) + so), (lptr)(dst + 64 * m), 16, 0, 0);
+    };
+    // the cut of this wave's share of G (tile in raw buffer `buf`): chunk (ks = v / 4, nb = v % 4) of the sample-packed image and
+    // chunk ks = v of the feature-packed image; returns the wave's bias-gradient contribution (rows 32 (v % 4) + i, samples 16 (v/4) + 8h ..)
+    const int rowc = swz_f4(i, 4 * (v >> 2) + 2 * h) + 256 * (v & 3), rowc1 = swz_f4(i, 4 * (v >> 2) + 2 * h + 1) + 256 * (v & 3);
+    int colf[8];                                                            // float index of G[16v + 8h + q][j]
+#pragma unroll
+    for (int q = 0; q < 8; ++q) colf[q] = swz_f4(16 * v + 8 * h + q, j >> 2) * 4 + (j & 3);
+    auto cut_g = [&](int buf, float dbv) {
+        const f32x4 lo = sbuf[buf * kBwd8Raw + rowc], hi = sbuf[buf * kBwd8Raw + rowc1];
+        f32x4 clo, chi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            clo[q] = sF[buf * 4 * kBwd8Raw + colf[q]];
+            chi[q] = sF[buf * 4 * kBwd8Raw + colf[4 + q]];
         }
+        u32x4_t p0, p1, p2;
+        cut3<false>(lo, hi, p0, p1, p2);
+        u32x4_t* pr = sP + kBwd8Prow + (v * 3) * 64 + lane;                 // chunk (ks, nb) = v
+        pr[0] = p0;
+        pr[64] = p1;
+        pr[128] = p2;
+        dbv = sum8(lo, hi, dbv);
+        cut3<false>(clo, chi, p0, p1, p2);
+        u32x4_t* pc = sP + kBwd8Pcol + (v * 3) * 64 + lane;                 // chunk ks = v
+        pc[0] = p0;
+        pc[64] = p1;
+        pc[128] = p2;
+        return dbv;
+    };
+    float dbacc = 0.0f;
+#if MVT_STAMP
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
+    const unsigned long long st_begin = st_last;
+#endif
+    dma_raw((int)blockIdx.x, 0);
+
+    if (v < 4) {
+        // ================================ Z waves: rows [32v, 32v+32) of dL/da ================================
+        const int w = v;
+        // this wave's quarter of the transposed weight stream (fp32-MFMA order: lane (i, h) of chunk (grp, w) holds
+        // W[32w + i][8 grp + 4h + e], e = 0..3), re-ordered to the bf16 operand (lane (i, h): W[32w + i][16 ks + 8h + q], q = 0..7)
+        // by one exchange between the lane halves, and cut into pieces once
+        u32x4_t wp[8][3];
+        {
+            const f32x4* ws = reinterpret_cast<const f32x4*>(wstream) + 64 * w + lane;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const f32x4 g0 = ws[256 * (2 * ks)], g1 = ws[256 * (2 * ks + 1)];       // n = 16ks + 4h + e  /  16ks + 8 + 4h + e
+                f32x4 lo, hi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float recv = __shfl_xor(h ? g0[e] : g1[e], 32);
+                    lo[e] = h ? recv : g0[e];               // h = 0: n = 16ks + e (own g0);        h = 1: n = 16ks + 8 + e (partner's g1)
+                    hi[e] = h ? g1[e] : recv;               // h = 0: n = 16ks + 4 + e (partner's g0); h = 1: n = 16ks + 12 + e (own g1)
+                }
+                cut3<false>(lo, hi, wp[ks][0], wp[ks][1], wp[ks][2]);
+            }
+        }
+        int eidx[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) eidx[e] = 4096 + swz_f4(32 * w + 4 * h + e, j >> 2) * 4 + (j & 3);   // a[row 32w + 4h + e (+8m)][sample j], raw buffer 0
+        if (!resid_tl) {                                        // no skip gradient: the residual image stays zero
+            const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sbuf[kBwd8Resid + 256 * w + 64 * m + lane] = z;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        int cur = 0;
+        for (int tile = (int)blockIdx.x; tile < n_tiles32; tile += stride) {
+            STAMP(5)
+            asm volatile("s_barrier" ::: "memory");             // B1: raw tile complete; pieces of the previous tile consumed
+            STAMP(0)
+            {
+                const int nt = tile + stride < n_tiles32 ? tile + stride : tile;
+                dma_raw(nt, cur ^ 1);
+            }
+            if (resid_tl) {
+                unsigned so = src_off;
+                asm volatile("" : "+v"(so));
+                const unsigned x = so >> 4;
+                const unsigned res_off = ((x & 56u) | ((x & 7u) ^ (x >> 3))) * 16u;      // lane * 16
+                f32x4* rdst = sbuf + kBwd8Resid + 256 * w;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    __builtin_amdgcn_global_load_lds((gptr)(sbase(resid_tl, (long)tile * 16384 + 4096 * w + 1024 * m) + res_off), (lptr)(rdst + 64 * m), 16, 0, 0);
+            }
+            dbacc = cut_g(cur, dbacc);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            STAMP(1)
+            asm volatile("s_barrier" ::: "memory");             // B2: both piece images complete
+            STAMP(2)
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const u32x4_t* pc = sP + kBwd8Pcol + lane;
+            u32x4_t b[3] = {pc[0], pc[64], pc[128]};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                u32x4_t bn[3];
+                if (ks < 7) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) bn[q] = pc[((ks + 1) * 3 + q) * 64];
+                }
+                acc = mfma16s(wp[ks][2], b[0], acc);
+                acc = mfma16s(wp[ks][1], b[1], acc);
+                acc = mfma16s(wp[ks][0], b[2], acc);
+                acc = mfma16s(wp[ks][1], b[0], acc);
+                acc = mfma16s(wp[ks][0], b[1], acc);
+                acc = mfma16s(wp[ks][0], b[0], acc);
+                if (ks < 7) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) b[q] = bn[q];
+                }
+            }
+            STAMP(3)
+            // the residual rows and the next raw tile have landed (they had the cut and the MFMA section); the previous stores too
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(4)
+            unsigned so = src_off;
+            asm volatile("" : "+v"(so));
+            const unsigned x = so >> 4;
+            const unsigned ln = (x & 56u) | ((x & 7u) ^ (x >> 3));
+            const unsigned oo = ((ln >> 5) * 128u + (ln & 31u)) * 4u;                     // ((4h) * 32 + j) floats
+            const float* sR = sF + 4 * kBwd8Resid + 32 * w * 32 + (oo >> 2);
+            char* optr = const_cast<char*>(sbase(da_tl, (long)tile * 16384 + 4096 * w));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = ((r & 3) + 8 * (r >> 2)) * 32;
+                const float av = sF[eidx[r & 3] + 8 * (r >> 2) * 32];
+                const float val = av > 0.0f ? acc[r] : 0.0f;
+                *(__attribute__((address_space(1))) float*)(optr + 4 * ro + oo) = val + sR[ro];
+            }
+            cur ^= 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) eidx[e] ^= 4 * kBwd8Raw;
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");        // end: all MFMA sections done, the sample-packed image is free
+        // bias gradient: rows 32 (v % 4) + i; this wave's samples [8h, 8h+8) of k-step 0 and, from wave v + 4, of k-step 1
+        float* xch = reinterpret_cast<float*>(sbuf + kBwd8Prow);
+        asm volatile("s_barrier" ::: "memory");                              // the W waves' partials are in xch
+        const float other = xch[64 * v + lane];
+        float sdb = dbacc + other;
+        sdb = sdb + __shfl_xor(sdb, 32);
+        if (h == 0) grad_out(db + (long)blockIdx.x * part_stride + 32 * v + i, sdb, part_stride != 0);
+    } else {
+        // ================================ W waves: rows [32u, 32u+32) of dW ================================
+        const int u = v - 4;
+        f32x16 dwacc[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dwacc[nb][r] = 0.0f;
+        int aidx[4];                                            // float4 index of the chunk pair (4ks + 2h, +1) of row 32u + i of a, raw buffer 0
+#pragma unroll
+        for (int e = 0; e < 4; ++e) aidx[e] = 1024 + 256 * u + swz_f4(i, 4 * (e >> 1) + 2 * h + (e & 1));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        int cur = 0;
+        for (int tile = (int)blockIdx.x; tile < n_tiles32; tile += stride) {
+            STAMP(5)
+            asm volatile("s_barrier" ::: "memory");             // B1
+            STAMP(0)
+            {
+                const int nt = tile + stride < n_tiles32 ? tile + stride : tile;
+                dma_raw(nt, cur ^ 1);
+            }
+            dbacc = cut_g(cur, dbacc);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            STAMP(1)
+            asm volatile("s_barrier" ::: "memory");             // B2
+            STAMP(2)
+            // this wave's own A operand (rows 32u + i of relu(a)) is cut behind the barrier: nobody waits for it
+            u32x4_t ap[2][3];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) cut3<true>(sbuf[aidx[2 * ks]], sbuf[aidx[2 * ks + 1]], ap[ks][0], ap[ks][1], ap[ks][2]);
+            const u32x4_t* pr = sP + kBwd8Prow + lane;
+            u32x4_t b[3] = {pr[0], pr[64], pr[128]};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {                       // chunk c = (ks = c / 4, nb = c % 4)
+                u32x4_t bn[3];
+                if (c < 7) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) bn[q] = pr[((c + 1) * 3 + q) * 64];
+                }
+                const int ks = c >> 2, nb = c & 3;
+                dwacc[nb] = mfma16s(ap[ks][2], b[0], dwacc[nb]);
+                dwacc[nb] = mfma16s(ap[ks][1], b[1], dwacc[nb]);
+                dwacc[nb] = mfma16s(ap[ks][0], b[2], dwacc[nb]);
+                dwacc[nb] = mfma16s(ap[ks][1], b[0], dwacc[nb]);
+                dwacc[nb] = mfma16s(ap[ks][0], b[1], dwacc[nb]);
+                dwacc[nb] = mfma16s(ap[ks][0], b[0], dwacc[nb]);
+                if (c < 7) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) b[q] = bn[q];
+                }
+            }
+            STAMP(3)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's part of the next raw tile has landed
+            STAMP(4)
+            cur ^= 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) aidx[e] ^= kBwd8Raw;
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        float* xch = reinterpret_cast<float*>(sbuf + kBwd8Prow);
+        xch[64 * u + lane] = dbacc;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int col = lane & 31, hh = lane >> 5;
+        const bool store = part_stride != 0;
+        float* dWo = dW + (long)blockIdx.x * part_stride;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) grad_out(dWo + (long)(32 * u + acc_row(r, hh)) * kHidden + 32 * nb + col, dwacc[nb][r], store);
     }
+#if MVT_STAMP
+    if (lane == 0 && blockIdx.x < 256) {
+        unsigned long long* o = g_bwd_stamp + ((long)blockIdx.x * 8 + v) * 8;
+        for (int q = 0; q < 6; ++q) o[q] = st_acc[q];
+        o[6] = __builtin_readcyclecounter() - st_begin;
+        o[7] = v < 4 ? 0 : 1;
+    }
+#endif
 }
 
 hipError_t launch_dense_bwd_fused(const float* g_tl, const float* a_tl, const float* wstream, const float* resid_tl,
                                   float* da_tl, long n_tiles, float* dW, float* db, int max_wgs, float* part, hipStream_t st) {
-    // (two-stage reduction of the 512 weight-gradient partials instead of the fp32 atomics: round 1 measured no difference in
-    // time; `part` != nullptr selects it for run-to-run identical gradients.  db sits directly behind dW: one span.)
-    const unsigned wgs = (unsigned)(n_tiles < max_wgs ? n_tiles : max_wgs);
-    if (!dW) {
-        hipLaunchKernelGGL(dense_bwd_fused_kernel<false>, dim3(wgs), dim3(256), 0, st, g_tl, a_tl, wstream, resid_tl, da_tl, n_tiles, dW, db, 0L);
+    // `part` != nullptr (deterministic mode): every workgroup stores its partial of the span [dW | db] (db directly behind dW) and
+    // launch_reduce_partials adds them in a fixed order; otherwise fp32 atomics straight onto the gradient.
+    static std::atomic<bool> attr_done{false};
+    if (!attr_done.load(std::memory_order_acquire)) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsBytes);
+        if (ea == hipSuccess)
+            ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_bwd_split8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBwd8LdsBytes);
+        if (ea != hipSuccess) return ea;
+        attr_done.store(true, std::memory_order_release);
+    }
+    if (n_tiles <= 0 || n_tiles > 0x7fffffffL) return hipErrorInvalidValue;                // tile indices are 32-bit inside the kernels
+    if (!dW) {                                             // frozen trunk (query_vjp): two 256-thread workgroups per CU
+        const unsigned wgs = (unsigned)(n_tiles < max_wgs ? n_tiles : max_wgs);
+        hipLaunchKernelGGL(dense_dx_kernel, dim3(wgs), dim3(256), kBwdLdsBytes, st, g_tl, a_tl, wstream, resid_tl, da_tl, n_tiles);
         return hipGetLastError();
     }
     if (part && db != dW + kHidden * kHidden) return hipErrorInvalidValue;
     const int span = kHidden * kHidden + kHidden;
-    hipLaunchKernelGGL(dense_bwd_fused_kernel<true>, dim3(wgs), dim3(256), 0, st, g_tl, a_tl, wstream, resid_tl, da_tl, n_tiles,
+    const unsigned wgs8 = (unsigned)(n_tiles < max_wgs / 2 ? n_tiles : max_wgs / 2);       // one 512-thread workgroup per CU
+    hipLaunchKernelGGL(dense_bwd_split8_kernel, dim3(wgs8), dim3(512), kBwd8LdsBytes, st, g_tl, a_tl, wstream, resid_tl, da_tl, n_tiles,
                        part ? part : dW, part ? part + kHidden * kHidden : db, part ? (long)span : 0L);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !part) return e;
-    return launch_reduce_partials(part, span, (int)wgs, span, dW, st);
+    return launch_reduce_partials(part, span, (int)wgs8, span, dW, st);
 }
 
 // ---- loss: d pred = 2 (pred - y) / n ; loss += sum (pred - y)^2 / n   (Keras MeanSquaredError) ----
