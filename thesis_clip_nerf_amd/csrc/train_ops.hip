@@ -1092,11 +1092,273 @@ __global__ __launch_bounds__(256) void dw0_kernel(FieldParams p, const float* __
     }
 }
 
+// ---- the same gradient with the GEMM on the bf16 matrix pipe (exactly cut operands), one 8-wave workgroup per CU -----------------
+// dw0_kernel above spends 768 fp32 MFMAs per tile (49 k matrix cycles), recomputes the geometry in each of its 12 waves and, like
+// every wave issuing v_mfma_f32_32x32x2_f32, cannot hide its gathers / lerps behind its own MFMAs.  Here, per tile of 32 samples:
+//   * X0 (384 rows x 32 samples) is built ONCE by the 512 threads, cut into three bf16 pieces and laid out in LDS in A-operand order
+//     (XA, 72 KiB); G is cut once into B-operand order (PB, 24 KiB) - as in dense_bwd_split8_kernel;
+//   * wave v owns output block nb = v % 4 of six row blocks (6 (v / 4) ..): 72 bf16 MFMAs per tile, 96 accumulator registers;
+//   * software pipeline over the workgroup's tiles: while the MFMAs of tile t run, the 64 feature taps per thread of tile t+1 are in
+//     flight to registers, wave 0 fills the PE table of tile t+1, wave 1 the geometry of tile t+2 and the rgb rows of tile t+1.
+struct GeomQ {            // what the gathers and lerps of a sample need, 16 bytes
+    float ax, ay;
+    int tl, pad;
+};
+constexpr int kPe8Row = 125;                                  // floats per sample of the PE + rgb table (odd: conflict-free)
+constexpr int kDw8XA = 0, kDw8PB = kDw8XA + 12 * 2 * 3 * 64, kDw8Raw = kDw8PB + 2 * 4 * 3 * 64, kDw8Pe = kDw8Raw + 1024;   // float4 units
+constexpr int kDw8Geom = kDw8Pe + (32 * kPe8Row + 3) / 4, kDw8GeomQ = kDw8Geom + 2 * 32 * 9 / 4;
+constexpr int kDw8LdsBytes = (kDw8GeomQ + 2 * 32) * 16;
+
+__global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const float* __restrict__ g0_tl, float* __restrict__ dW0,
+                                                            float* __restrict__ db0, long part_stride) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 sbuf[];
+    using gptr = const __attribute__((address_space(1))) void*;
+    using lptr = __attribute__((address_space(3))) void*;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
+    u32x4_t* sP = reinterpret_cast<u32x4_t*>(sbuf);
+    const float* sF = reinterpret_cast<const float*>(sbuf);
+    float* pe_tab = reinterpret_cast<float*>(sbuf + kDw8Pe);
+    SampleGeom* geom = reinterpret_cast<SampleGeom*>(sbuf + kDw8Geom);          // [2][32]
+    GeomQ* geomq = reinterpret_cast<GeomQ*>(sbuf + kDw8GeomQ);                  // [2][32]
+    const int view_tiles = (int)(p.n_tiles * p.V), stride = (int)gridDim.x;
+    auto sum8 = [](const f32x4& lo, const f32x4& hi, float accv) {
+        float s = lo[0];
+        const float t[7] = {lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int q = 0; q < 7; ++q) asm("v_add_f32_e32 %0, %1, %2" : "=v"(s) : "v"(s), "v"(t[q]));
+        asm("v_add_f32_e32 %0, %1, %2" : "=v"(accv) : "v"(accv), "v"(s));
+        return accv;
+    };
+    // ---- the pieces of work of one tile ----
+    auto do_geom = [&](int tile, int slot) {                  // one wave, lanes 0..31: sample i of the view tile
+        if (h == 0) {
+            const ViewRow vr = view_row(p, (long)tile * 32 + i);
+            const int ray = vr.ray, b = vr.bv;
+            const float* E = p.einv + 16 * b;
+            const float zz = p.z[vr.g];
+            const float dx = p.rays_d[3 * ray], dy = p.rays_d[3 * ray + 1], dz = p.rays_d[3 * ray + 2];
+            const float wx = p.rays_o[3 * ray] + zz * dx, wy = p.rays_o[3 * ray + 1] + zz * dy, wz = p.rays_o[3 * ray + 2] + zz * dz;
+            float cam[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cam[r] = row_dot4(E, r, wx, wy, wz, 1.0f);
+            float px, py;
+            pixel_from_cam(p.k4 + 16 * b, cam, &px, &py);
+            const Taps tp = bilinear_taps(px, py, p.H, p.W);
+            SampleGeom sg;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                sg.cam[r] = cam[r];
+                sg.dir[r] = row_dot4(E, r, dx, dy, dz, 1.0f);
+            }
+            sg.ax = tp.ax;
+            sg.ay = tp.ay;
+            sg.tl = (b * p.H + tp.y0) * p.W + tp.x0;
+            geom[slot * 32 + i] = sg;
+            GeomQ gq;
+            gq.ax = tp.ax;
+            gq.ay = tp.ay;
+            gq.tl = sg.tl;
+            gq.pad = 0;
+            geomq[slot * 32 + i] = gq;
+        }
+    };
+    auto do_pe = [&](int slot) {                              // one wave: lane (sample i, half h): h = 0 the camera point, h = 1 the direction
+        const SampleGeom sgm = geom[slot * 32 + i];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float a0 = (h ? sgm.dir[d] : sgm.cam[d]) * 3.14159274101257324f;
+            float sk = 0.0f, ck = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kNFreq; ++k) {
+                if (k == 0 || k == 5) {
+                    sincos_f32(a0 * (float)(1 << k), &sk, &ck);
+                } else {                                      // octave k is the double angle of octave k - 1 (field_eval.hip)
+                    const float s2 = sk + sk;
+                    const float cn = fmaf(-s2, sk, 1.0f);
+                    sk = s2 * ck;
+                    ck = cn;
+                }
+                pe_tab[i * kPe8Row + 60 * h + 20 * d + 2 * k] = sk;
+                pe_tab[i * kPe8Row + 60 * h + 20 * d + 2 * k + 1] = ck;
+            }
+        }
+    };
+    auto do_rgb = [&](int slot) {                             // one wave, lanes 0..31: rows 120..122 of sample i
+        if (h == 0) {
+            const GeomQ gq = geomq[slot * 32 + i];
+            const float* im = p.images + 3 * (long)gq.tl;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                pe_tab[i * kPe8Row + 120 + c] = bilerp(im[c] * 2.0f - 1.0f, im[3 + c] * 2.0f - 1.0f, im[3 * p.W + c] * 2.0f - 1.0f,
+                                                       im[3 * p.W + 3 + c] * 2.0f - 1.0f, gq.ax, gq.ay);
+        }
+    };
+    // feature rows: thread = (channel c = tid % 256, sample-group parity tid / 256); pass ps covers samples 8 (2 ps + tid / 256) + q
+    const int fc = tid & 255, fsg = tid >> 8;
+    float tap[2][8][4];
+    auto issue_gathers = [&](int slot) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int tl = __builtin_amdgcn_readfirstlane(geomq[slot * 32 + 8 * (2 * ps + fsg) + q].tl);
+                const float* f = p.features + 256 * (long)tl + fc;
+                tap[ps][q][0] = f[0];
+                tap[ps][q][1] = f[256];
+                tap[ps][q][2] = f[256 * (long)p.W];
+                tap[ps][q][3] = f[256 * (long)p.W + 256];
+            }
+    };
+    auto dma_g = [&](int tile) {                              // raw G tile, XOR-swizzled on the source side (dense_dx_kernel): 2 wave-instructions per wave
+        const unsigned so = (unsigned)((lane & 56) + ((lane & 7) ^ (lane >> 3))) * 16u;
+        const char* src = reinterpret_cast<const char*>(g0_tl) + (long)tile * 16384 + 2048 * v;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+            __builtin_amdgcn_global_load_lds((gptr)(src + 1024 * m + so), (lptr)(sbuf + kDw8Raw + 128 * v + 64 * m), 16, 0, 0);
+    };
+    float dbacc = 0.0f;
+    auto build = [&](int slot, bool count_db) {               // everything of a tile that goes into XA / PB
+        // feature rows 123 + c: the two units (k-step ps, half fsg) of this thread's channel
+        const int r = 123 + fc, kb = r >> 5, li = (r & 31) + 32 * fsg;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            f32x4 lo, hi;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const GeomQ gq = geomq[slot * 32 + 8 * (2 * ps + fsg) + q];
+                const float val = bilerp(tap[ps][q][0], tap[ps][q][1], tap[ps][q][2], tap[ps][q][3], gq.ax, gq.ay);
+                if (q < 4) lo[q] = val;
+                else hi[q - 4] = val;
+            }
+            u32x4_t p0, p1, p2;
+            cut3<false>(lo, hi, p0, p1, p2);
+            u32x4_t* xa = sP + kDw8XA + ((kb * 2 + ps) * 3) * 64 + li;
+            xa[0] = p0;
+            xa[64] = p1;
+            xa[128] = p2;
+        }
+        // rows 0..122 from the PE + rgb table: thread = (row tid % 128, sample group tid / 128)
+        {
+            const int pr = tid & 127, sg = tid >> 7;
+            if (pr < 123) {
+                f32x4 lo, hi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    lo[q] = pe_tab[(8 * sg + q) * kPe8Row + pr];
+                    hi[q] = pe_tab[(8 * sg + 4 + q) * kPe8Row + pr];
+                }
+                u32x4_t p0, p1, p2;
+                cut3<false>(lo, hi, p0, p1, p2);
+                u32x4_t* xa = sP + kDw8XA + (((pr >> 5) * 2 + (sg >> 1)) * 3) * 64 + (pr & 31) + 32 * (sg & 1);
+                xa[0] = p0;
+                xa[64] = p1;
+                xa[128] = p2;
+            }
+        }
+        // G: chunk (ks = v / 4, nb = v % 4) of the sample-packed image, and this wave's share of the bias gradient
+        {
+            const f32x4 lo = sbuf[kDw8Raw + swz_f4(i, 4 * (v >> 2) + 2 * h) + 256 * (v & 3)];
+            const f32x4 hi = sbuf[kDw8Raw + swz_f4(i, 4 * (v >> 2) + 2 * h + 1) + 256 * (v & 3)];
+            u32x4_t p0, p1, p2;
+            cut3<false>(lo, hi, p0, p1, p2);
+            u32x4_t* pb = sP + kDw8PB + (v * 3) * 64 + lane;
+            pb[0] = p0;
+            pb[64] = p1;
+            pb[128] = p2;
+            if (count_db) dbacc = sum8(lo, hi, dbacc);        // (not for the clamped re-build behind the last tile)
+        }
+    };
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+    // rows 379..383 do not exist: their XA slots (row block 11, rows 27..31) stay zero
+    for (int q = tid; q < 12 * 2 * 3 * 64; q += 512) sP[kDw8XA + q] = u32x4_t{0u, 0u, 0u, 0u};
+    // ---- prologue: tile t0 built, geometry of t1 ready ----
+    const int t0 = (int)blockIdx.x;
+    const int t1 = t0 + stride < view_tiles ? t0 + stride : t0;
+    dma_g(t0);
+    if (v == 0) do_geom(t0, 0);
+    if (v == 1) do_geom(t1, 1);
+    __syncthreads();
+    if (v == 0) do_pe(0);
+    if (v == 1) do_rgb(0);
+    issue_gathers(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    build(0, true);
+    int it = 0;
+    for (int tile = t0; tile < view_tiles; tile += stride, ++it) {
+        const int cur = it & 1;
+        const int tn = tile + stride < view_tiles ? tile + stride : tile;          // next tile (clamped: a harmless rebuild at the end)
+        const int tnn = tn + stride < view_tiles ? tn + stride : tn;
+        __syncthreads();                                       // B_a: XA, PB of `tile` complete; geometry of tn in slot cur ^ 1
+        dma_g(tn);
+        issue_gathers(cur ^ 1);
+        if (v == 0) do_pe(cur ^ 1);
+        if (v == 1) {
+            do_geom(tnn, cur);
+            do_rgb(cur ^ 1);
+        }
+        // ---- 72 MFMAs: output block nb = v % 4 of row blocks 6 (v / 4) + {0..5} ----
+        {
+            const int nb = v & 3;
+            const u32x4_t* pb = sP + kDw8PB + lane;
+            u32x4_t b[2][3];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) b[ks][q] = pb[((ks * 4 + nb) * 3 + q) * 64];
+            const u32x4_t* xa = sP + kDw8XA + (6 * (v >> 2)) * 2 * 3 * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const u32x4_t a0 = xa[((k * 2 + ks) * 3 + 0) * 64], a1 = xa[((k * 2 + ks) * 3 + 1) * 64], a2 = xa[((k * 2 + ks) * 3 + 2) * 64];
+                    acc[k] = mfma16s(a2, b[ks][0], acc[k]);
+                    acc[k] = mfma16s(a1, b[ks][1], acc[k]);
+                    acc[k] = mfma16s(a0, b[ks][2], acc[k]);
+                    acc[k] = mfma16s(a1, b[ks][0], acc[k]);
+                    acc[k] = mfma16s(a0, b[ks][1], acc[k]);
+                    acc[k] = mfma16s(a0, b[ks][0], acc[k]);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // taps and G of the next tile have landed
+        __syncthreads();                                       // B_b: every wave is done reading XA / PB; PE table of tn complete
+        build(cur ^ 1, tile + stride < view_tiles);
+    }
+    __syncthreads();
+    // ---- outputs ----
+    float* xch = reinterpret_cast<float*>(sbuf + kDw8PB);     // bias gradient: waves v and v + 4 hold the two k-steps of block v % 4
+    if (v >= 4) xch[64 * (v - 4) + lane] = dbacc;
+    __syncthreads();
+    const bool store = part_stride != 0;
+    dW0 += (long)blockIdx.x * part_stride;
+    db0 += (long)blockIdx.x * part_stride;
+    if (v < 4) {
+        float sdb = dbacc + xch[64 * v + lane];
+        sdb = sdb + __shfl_xor(sdb, 32);
+        if (h == 0) grad_out(db0 + 32 * v + i, sdb, store);
+    }
+    const int col = lane & 31, hh = lane >> 5, nb = v & 3;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * (6 * (v >> 2) + k) + acc_row(r, hh);
+            if (row < kIn) grad_out(dW0 + (long)row * kHidden + 32 * nb + col, acc[k][r], store);
+        }
+}
+
+#ifndef MVT_DW0_SPLIT8
+#define MVT_DW0_SPLIT8 1   // 1: dw0_split8_kernel; 0: dw0_kernel (fp32 MFMA, two launches)
+#endif
 hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, float* db0, int max_wgs, float* part, hipStream_t st) {
     const long view_tiles = p.n_tiles * p.V;
-    const unsigned wgs = (unsigned)(view_tiles < max_wgs ? view_tiles : max_wgs);
-    // two launches: row blocks 0..3 (PE rows; 62 KiB of PE tables per workgroup) and row blocks 4..11 (feature rows, no
-    // dynamic LDS, full occupancy)
+    if (view_tiles <= 0 || view_tiles > 0x7fffffffL) return hipErrorInvalidValue;
     static std::atomic<bool> attr_done[16];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -1105,6 +1367,8 @@ hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, floa
     if (dev >= 0 && dev < 16 && !attr_done[dev].load(std::memory_order_acquire)) {
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pe_bytes)) != hipSuccess)
             return e;
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw0_split8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDw8LdsBytes)) != hipSuccess)
+            return e;
         attr_done[dev].store(true, std::memory_order_release);
     }
     if (part && db0 != dW0 + kIn * kHidden) return hipErrorInvalidValue;       // one span [dW0 | db0]
@@ -1112,8 +1376,16 @@ hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, floa
     float* dWk = part ? part : dW0;
     float* dbk = part ? part + kIn * kHidden : db0;
     const long stride = part ? span : 0;
+#if MVT_DW0_SPLIT8
+    const unsigned wgs = (unsigned)(view_tiles < max_wgs / 2 ? view_tiles : max_wgs / 2);      // one 512-thread workgroup per CU
+    hipLaunchKernelGGL(dw0_split8_kernel, dim3(wgs), dim3(512), kDw8LdsBytes, st, p, g0_tl, dWk, dbk, stride);
+#else
+    // two launches: row blocks 0..3 (PE rows; 62 KiB of PE tables per workgroup) and row blocks 4..11 (feature rows, no
+    // dynamic LDS, full occupancy)
+    const unsigned wgs = (unsigned)(view_tiles < max_wgs ? view_tiles : max_wgs);
     hipLaunchKernelGGL(dw0_kernel, dim3(wgs, 1), dim3(256), pe_bytes, st, p, g0_tl, dWk, dbk, 0, stride);
     hipLaunchKernelGGL(dw0_kernel, dim3(wgs, 2), dim3(256), 0, st, p, g0_tl, dWk, dbk, 1, stride);
+#endif
     e = hipGetLastError();
     if (e != hipSuccess || !part) return e;
     return launch_reduce_partials(part, stride, (int)wgs, span, dW0, st);
