@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(256) void dw0_kernel(FieldParams p, const float* __
 //     (XA, 72 KiB); G is cut once into B-operand order (PB, 24 KiB) - as in dense_bwd_split8_kernel;
 //   * wave v owns output block nb = v % 4 of six row blocks (6 (v / 4) ..): 72 bf16 MFMAs per tile, 96 accumulator registers;
 //   * software pipeline over the workgroup's tiles: while the MFMAs of tile t run, the 64 feature taps per thread of tile t+1 are in
-//     flight to registers, wave 0 fills the PE table of tile t+1, wave 1 the geometry of tile t+2 and the rgb rows of tile t+1.
+//     flight to registers and the PE table / rgb rows of tile t+1 and the geometry of tile t+2 are filled (spread over all threads).
 struct GeomQ {            // what the gathers and lerps of a sample need, 16 bytes
     float ax, ay;
     int tl, pad;
@@ -1109,6 +1109,9 @@ constexpr int kDw8XA = 0, kDw8PB = kDw8XA + 12 * 2 * 3 * 64, kDw8Raw = kDw8PB + 
 constexpr int kDw8Geom = kDw8Pe + (32 * kPe8Row + 3) / 4, kDw8GeomQ = kDw8Geom + 2 * 32 * 9 / 4;
 constexpr int kDw8LdsBytes = (kDw8GeomQ + 2 * 32) * 16;
 
+#ifndef MVT_DW0_ABL
+#define MVT_DW0_ABL 0      // timing-only ablations (wrong results), bits: 1 no feature gathers, 2 no PE / rgb / geometry, 4 no MFMAs, 8 no build
+#endif
 __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const float* __restrict__ g0_tl, float* __restrict__ dW0,
                                                             float* __restrict__ db0, long part_stride) {
     extern __shared__ __attribute__((aligned(16))) f32x4 sbuf[];
@@ -1131,8 +1134,8 @@ __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const
         return accv;
     };
     // ---- the pieces of work of one tile ----
-    auto do_geom = [&](int tile, int slot) {                  // one wave, lanes 0..31: sample i of the view tile
-        if (h == 0) {
+    auto do_geom = [&](int tile, int slot) {                  // threads 480..511 (upper half of wave 7): sample i of the view tile
+        if (tid >= 480) {
             const ViewRow vr = view_row(p, (long)tile * 32 + i);
             const int ray = vr.ray, b = vr.bv;
             const float* E = p.einv + 16 * b;
@@ -1163,35 +1166,36 @@ __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const
             geomq[slot * 32 + i] = gq;
         }
     };
-    auto do_pe = [&](int slot) {                              // one wave: lane (sample i, half h): h = 0 the camera point, h = 1 the direction
-        const SampleGeom sgm = geom[slot * 32 + i];
+    // PE rows of the table, spread over threads 0..383: thread = (sample tid % 32, source tid / 32 % 6 = {cam x,y,z, dir x,y,z},
+    // half of the octaves tid / 192): one accurate sin/cos (octave 0 or 5) and the double-angle recurrence for the next four
+    auto do_pe = [&](int slot) {
+        if (tid < 384) {
+            const int smp = tid & 31, src = (tid >> 5) % 6, half = tid / 192;
+            const SampleGeom sgm = geom[slot * 32 + smp];
+            const float x = src == 0 ? sgm.cam[0] : src == 1 ? sgm.cam[1] : src == 2 ? sgm.cam[2] : src == 3 ? sgm.dir[0] : src == 4 ? sgm.dir[1] : sgm.dir[2];
+            const float a0 = x * 3.14159274101257324f;
+            float sk, ck;
+            sincos_f32(a0 * (half ? 32.0f : 1.0f), &sk, &ck);
+            float* dst = pe_tab + smp * kPe8Row + 20 * src + 10 * half;       // rows 60 (src / 3) + 20 (src % 3) + 2k + {sin, cos} = 20 src + 2k
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float a0 = (h ? sgm.dir[d] : sgm.cam[d]) * 3.14159274101257324f;
-            float sk = 0.0f, ck = 0.0f;
-#pragma unroll
-            for (int k = 0; k < kNFreq; ++k) {
-                if (k == 0 || k == 5) {
-                    sincos_f32(a0 * (float)(1 << k), &sk, &ck);
-                } else {                                      // octave k is the double angle of octave k - 1 (field_eval.hip)
-                    const float s2 = sk + sk;
-                    const float cn = fmaf(-s2, sk, 1.0f);
-                    sk = s2 * ck;
-                    ck = cn;
-                }
-                pe_tab[i * kPe8Row + 60 * h + 20 * d + 2 * k] = sk;
-                pe_tab[i * kPe8Row + 60 * h + 20 * d + 2 * k + 1] = ck;
+            for (int k = 0; k < 5; ++k) {
+                dst[2 * k] = sk;
+                dst[2 * k + 1] = ck;
+                const float s2 = sk + sk;                     // octave k + 1 is the double angle of octave k (field_eval.hip)
+                const float cn = fmaf(-s2, sk, 1.0f);
+                sk = s2 * ck;
+                ck = cn;
             }
         }
     };
-    auto do_rgb = [&](int slot) {                             // one wave, lanes 0..31: rows 120..122 of sample i
-        if (h == 0) {
-            const GeomQ gq = geomq[slot * 32 + i];
-            const float* im = p.images + 3 * (long)gq.tl;
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                pe_tab[i * kPe8Row + 120 + c] = bilerp(im[c] * 2.0f - 1.0f, im[3 + c] * 2.0f - 1.0f, im[3 * p.W + c] * 2.0f - 1.0f,
-                                                       im[3 * p.W + 3 + c] * 2.0f - 1.0f, gq.ax, gq.ay);
+    // rgb rows 120..122: threads 384..479 = (sample, channel)
+    auto do_rgb = [&](int slot) {
+        if (tid >= 384 && tid < 480) {
+            const int q = tid - 384, smp = q & 31, c = q >> 5;
+            const GeomQ gq = geomq[slot * 32 + smp];
+            const float* im = p.images + 3 * (long)gq.tl + c;
+            pe_tab[smp * kPe8Row + 120 + c] = bilerp(im[0] * 2.0f - 1.0f, im[3] * 2.0f - 1.0f, im[3 * p.W] * 2.0f - 1.0f,
+                                                     im[3 * p.W + 3] * 2.0f - 1.0f, gq.ax, gq.ay);
         }
     };
     // feature rows: thread = (channel c = tid % 256, sample-group parity tid / 256); pass ps covers samples 8 (2 ps + tid / 256) + q
@@ -1227,7 +1231,10 @@ __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const GeomQ gq = geomq[slot * 32 + 8 * (2 * ps + fsg) + q];
-                const float val = bilerp(tap[ps][q][0], tap[ps][q][1], tap[ps][q][2], tap[ps][q][3], gq.ax, gq.ay);
+                // (fused multiply-adds: the recomputed input does not have to round like the forward's lerp)
+                const float top = fmaf(gq.ax, tap[ps][q][1] - tap[ps][q][0], tap[ps][q][0]);
+                const float bot = fmaf(gq.ax, tap[ps][q][3] - tap[ps][q][2], tap[ps][q][2]);
+                const float val = fmaf(gq.ay, bot - top, top);
                 if (q < 4) lo[q] = val;
                 else hi[q - 4] = val;
             }
@@ -1281,11 +1288,11 @@ __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const
     const int t0 = (int)blockIdx.x;
     const int t1 = t0 + stride < view_tiles ? t0 + stride : t0;
     dma_g(t0);
-    if (v == 0) do_geom(t0, 0);
-    if (v == 1) do_geom(t1, 1);
+    do_geom(t0, 0);
+    do_geom(t1, 1);
     __syncthreads();
-    if (v == 0) do_pe(0);
-    if (v == 1) do_rgb(0);
+    do_pe(0);
+    do_rgb(0);
     issue_gathers(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1297,14 +1304,14 @@ __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const
         const int tnn = tn + stride < view_tiles ? tn + stride : tn;
         __syncthreads();                                       // B_a: XA, PB of `tile` complete; geometry of tn in slot cur ^ 1
         dma_g(tn);
-        issue_gathers(cur ^ 1);
-        if (v == 0) do_pe(cur ^ 1);
-        if (v == 1) {
-            do_geom(tnn, cur);
+        if (!(MVT_DW0_ABL & 1)) issue_gathers(cur ^ 1);
+        if (!(MVT_DW0_ABL & 2)) {
+            do_pe(cur ^ 1);
             do_rgb(cur ^ 1);
+            do_geom(tnn, cur);
         }
         // ---- 72 MFMAs: output block nb = v % 4 of row blocks 6 (v / 4) + {0..5} ----
-        {
+        if (!(MVT_DW0_ABL & 4)) {
             const int nb = v & 3;
             const u32x4_t* pb = sP + kDw8PB + lane;
             u32x4_t b[2][3];
@@ -1328,7 +1335,7 @@ __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // taps and G of the next tile have landed
         __syncthreads();                                       // B_b: every wave is done reading XA / PB; PE table of tn complete
-        build(cur ^ 1, tile + stride < view_tiles);
+        if (!(MVT_DW0_ABL & 8)) build(cur ^ 1, tile + stride < view_tiles);
     }
     __syncthreads();
     // ---- outputs ----
