@@ -142,6 +142,35 @@ def test_loss_and_grads_match_torch_oracle(batch, views, stop):
         assert np.linalg.norm(got - gc_ref) < 0.2 * np.linalg.norm(gc_cut - gc_ref)
 
 
+@pytest.mark.parametrize('batch,views', [(1, 1), (2, 2)])
+def test_sample_position_gradient_through_the_texel_table_matches_the_recomputed_one(batch, views, monkeypatch):
+    """mvnerf_field_backward_table: with the forward's texel table the feature rows' part of dL/dz is g0 . d(lerp of table rows);
+    without it W0 . g0 is recomputed over the 256 channels.  Both feed the coarse net through resample_bwd (stop=False)."""
+    sc = make_scene(seed=77 + views, batch=batch, n_views=views, height=16, width=16, n_rays=32, bias_scale=0.05)
+    y = np.random.default_rng(3).random((batch, 32, 3)).astype(np.float32)
+    inputs = tuple(sc[k] for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'])
+    grads = {}
+    for use_table in (True, False):
+        monkeypatch.setattr(ops, 'texel_table_pays', lambda *a, _u=use_table: _u)
+        m = MVVNeRFRenderer(32, 32, n_views=views, batch_size=batch, near=sc['near'], far=sc['far'], device=DEV)
+        m.set_weights(sc['coarse'], sc['fine'])
+        _, grad, _ = m.loss_and_grads(inputs, y, sc['features'], u_coarse=dev(sc['u_coarse']), u_fine=dev(sc['u_fine']), stop_fine_z=False)
+        torch.cuda.synchronize()
+        grads[use_table] = grad.cpu().numpy().copy()
+    a, b = grads[True][:247300], grads[False][:247300]              # the coarse net sees dL/dz of the fine pass
+    assert np.linalg.norm(b) > 0
+    # (the forward value itself differs in the last bits with and without the table, and this term has a gain of pi * 2^9 through
+    # the positional encoding: torch's own fp32 autograd is 1.8e-2 away from fp64 on such scenes; measured here 1e-3 .. 2e-3)
+    assert np.linalg.norm(a - b) < 1e-2 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
+    # and the two differ from the gradient with the fine depths held constant, i.e. the term is really there
+    monkeypatch.setattr(ops, 'texel_table_pays', lambda *a: True)
+    m = MVVNeRFRenderer(32, 32, n_views=views, batch_size=batch, near=sc['near'], far=sc['far'], device=DEV)
+    m.set_weights(sc['coarse'], sc['fine'])
+    _, grad_cut, _ = m.loss_and_grads(inputs, y, sc['features'], u_coarse=dev(sc['u_coarse']), u_fine=dev(sc['u_fine']), stop_fine_z=True)
+    cut = grad_cut.cpu().numpy()[:247300]
+    assert np.linalg.norm(a - b) < 0.05 * np.linalg.norm(a - cut)
+
+
 def test_train_step_reduces_loss_and_respects_q9():
     sc = make_scene(seed=50, batch=1, n_views=1, height=16, width=16, n_rays=64, bias_scale=0.0)
     y = np.random.default_rng(3).random((1, 64, 3)).astype(np.float32)

@@ -1408,10 +1408,17 @@ constexpr int kDfeRow = 257;       // floats per sample row of the LDS image (od
 
 // Query mode (d_o / d_d given): the same chain ends in dL/d(ray origin) and dL/d(ray direction) per ray
 // instead of dL/dz - the PE(cam dir) rows 60..119 then count too (cam dir = E^-1 [d; 1], Q3).
+//
+// kTable (p.texel_table given, d_features not wanted): the 256 feature rows never appear.  With T[texel] = W0[123:379]^T f[texel]
+// (the forward's texel table, project_texels_kernel) the feature part of dL/d(ax, ay) is g0 . d(lerp of T rows)/d(ax, ay): four
+// 128-float table rows per sample and two dot products with g0 instead of two of the three 128 x 128 slab GEMMs, the LDS image and
+// 4 x 256 feature taps per sample (990 -> 260 us at 4096 x 128 samples).  A lane (sample j, half h) holds g0 in accumulator order,
+// which is the order of its half of a table row.
+template <bool kTable>
 __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const float* __restrict__ g0_tl,
-                                                          const float* __restrict__ w0t_streams, float* __restrict__ d_z,
-                                                          float* __restrict__ d_o, float* __restrict__ d_d,
-                                                          float* __restrict__ d_features) {
+                                                                       const float* __restrict__ w0t_streams, float* __restrict__ d_z,
+                                                                       float* __restrict__ d_o, float* __restrict__ d_d,
+                                                                       float* __restrict__ d_features) {
     extern __shared__ __attribute__((aligned(16))) float lds_dz[];
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1455,7 +1462,7 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
     float dcam[3] = {0.0f, 0.0f, 0.0f}, dcdir[3] = {0.0f, 0.0f, 0.0f};
     float dax = 0.0f, day = 0.0f;
 #pragma unroll 1
-    for (int slab = 0; slab < 3; ++slab) {
+    for (int slab = 0; slab < (kTable ? 1 : 3); ++slab) {
         f32x16 acc[4];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
@@ -1508,19 +1515,52 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
                                 dq = im[3 * p.W + 3] * 2.0f - 1.0f;
                     dax += v * ((1.0f - tp.ay) * (bq - a) + tp.ay * (dq - cq));
                     day += v * ((cq - a) + tp.ax * ((dq - cq) - (bq - a)));
-                } else if (row >= 123 && row < 379) {
+                } else if (!kTable && row >= 123 && row < 379) {
                     dfe[j * kDfeRow + (row - 123)] = v;
                 }
             }
     }
-    if (lane < 32) {
+    if (kTable) {
+        // this lane's half (64 h .. 64 h + 63, accumulator order: 16 nb + r <-> feature 32 nb + acc_row(r, h)) of the four table rows
+        const f32x4* T = reinterpret_cast<const f32x4*>(p.texel_table) + 32 * (long)tl + 16 * h;
+        const long rowstep = 32 * (long)p.W;
+        const float one_m_ay = 1.0f - tp.ay;
+        float pa = 0.0f, pb = 0.0f;
+        asm volatile("" ::: "memory");                      // the table loads stay behind the slab GEMM (register budget: 2 waves / SIMD)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            f32x4 trow[4][4];                               // one output block at a time: 16 loads in flight
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                trow[q][0] = T[4 * nb + q];
+                trow[q][1] = T[32 + 4 * nb + q];
+                trow[q][2] = T[rowstep + 4 * nb + q];
+                trow[q][3] = T[rowstep + 32 + 4 * nb + q];
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 ttl = trow[q][0], ttr = trow[q][1], tbl = trow[q][2], tbr = trow[q][3];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float gv = bin[nb][4 * q + c];
+                    const float dt = ttr[c] - ttl[c], db = tbr[c] - tbl[c];
+                    pa += gv * (one_m_ay * dt + tp.ay * db);
+                    pb += gv * ((tbl[c] - ttl[c]) + tp.ax * (db - dt));
+                }
+            }
+        }
+        dax += pa;                                          // (the two halves are added below)
+        day += pb;
+    }
+    if (!kTable && lane < 32) {
         dax_s[lane] = 0.0f;
         day_s[lane] = 0.0f;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // feature channels, lane = channel (4 passes of 64), one sample at a time: coalesced tap reads
 #pragma unroll 1
-    for (int sidx = 0; sidx < 32; ++sidx) {
+    for (int sidx = 0; sidx < (kTable ? 0 : 32); ++sidx) {
         const int tls = __shfl(tl, sidx);
         const float axs = __shfl(tp.ax, sidx), ays = __shfl(tp.ay, sidx);
         const float* f = p.features + 256 * (long)tls;
@@ -1559,8 +1599,10 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
     for (int d = 0; d < 3; ++d) dcam[d] += __shfl_xor(dcam[d], 32);
     dax += __shfl_xor(dax, 32);
     day += __shfl_xor(day, 32);
-    dax += dax_s[j];
-    day += day_s[j];
+    if (!kTable) {
+        dax += dax_s[j];
+        day += day_s[j];
+    }
     // clamps (torch.clamp semantics: gradient passes inside the closed range)
     const float dpx = (ux >= 0.0f && ux <= 1.0f && pxr >= -1e6f && pxr <= 1e6f) ? dax : 0.0f;
     const float dpy = (uy >= 0.0f && uy <= 1.0f && pyr >= -1e6f && pyr <= 1e6f) ? day : 0.0f;
@@ -1589,18 +1631,23 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
 
 hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, float* d_o,
                            float* d_d, float* d_features, hipStream_t st) {
+    const unsigned wgs = (unsigned)((p.n_tiles * p.V + 3) / 4);
+    if (p.texel_table && !d_features) {                   // feature rows through the forward's texel table, no LDS
+        hipLaunchKernelGGL(field_dz_kernel<true>, dim3(wgs), dim3(256), 0, st, p, g0_tl, w0t_streams, d_z, d_o, d_d, d_features);
+        return hipGetLastError();
+    }
     const size_t lds_bytes = (size_t)4 * (32 * kDfeRow + 64) * sizeof(float);
     static std::atomic<bool> attr_done[16];      // first call per device sets the dynamic-LDS limit (idempotent)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 16 && !attr_done[dev].load(std::memory_order_acquire)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_dz_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&field_dz_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes);
         if (e != hipSuccess) return e;
         attr_done[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(field_dz_kernel, dim3((unsigned)((p.n_tiles * p.V + 3) / 4)), dim3(256), lds_bytes, st, p, g0_tl, w0t_streams, d_z, d_o, d_d, d_features);
+    hipLaunchKernelGGL(field_dz_kernel<false>, dim3(wgs), dim3(256), lds_bytes, st, p, g0_tl, w0t_streams, d_z, d_o, d_d, d_features);
     return hipGetLastError();
 }
 

@@ -259,7 +259,7 @@ class MVVNeRFRenderer:
             d_rgbs_f, d_z_all = ops.composite_bwd(z_all, rgbs_f, d_fine, return_dz=True)
         d_feat = torch.zeros_like(feats) if return_d_features else None
         tb['scratch'] = ops.field_backward(rays_o, rays_d, z_all, *geo, self.fine_net, self._packed_bwd[1], tb['stash_f'],
-                                           rgbs_f, d_rgbs_f, gf, tb.get('scratch'), d_z=d_z_all, d_features=d_feat)
+                                           rgbs_f, d_rgbs_f, gf, tb.get('scratch'), d_z=d_z_all, d_features=d_feat, texel_table=tab_f)
         if not stop_fine_z:
             d_w = ops.resample_bwd(z, w, self._dev(u_fine), rank, d_z_all, self.q7_mode)
         d_rgbs_c = ops.composite_bwd(z, rgbs_c, d_rgb, d_weights=d_w)
