@@ -223,11 +223,11 @@ int mvnerf_finish_view(const float* rgb, const float* depth, long n, float* minm
 /* Bytes of the activation stash one mvnerf_field_eval_stash call writes (7 per-view + 7 fused pre-activation
  * tensors in tile layout). */
 size_t mvnerf_stash_bytes(int B, int V, int R, int S);
-/* Weight-gradient reduction mode of mvnerf_field_backward (process-wide, default 0): 0 = every workgroup adds its partial
- * with fp32 atomics (fastest; the arrival order, hence the last bits of the gradient, varies from run to run); 1 = the
- * partials are stored and summed in workgroup order (bit-identical gradients for identical inputs).  Returns the previous
- * mode.  The gradients w.r.t. sample depths (V > 1), ray origins / directions and the source feature maps still accumulate
- * with atomics. */
+/* Weight-gradient reduction of mvnerf_field_backward: every workgroup stores its partial of a layer's [dW | db] span and the partials
+ * are summed in workgroup order - bit-identical gradients for identical inputs.  Until the middle of round 2 this was a mode (0 =
+ * fp32 atomics, 1 = stored partials); with the partials added by a parallel fixed-order reduction it is also the faster of the two
+ * and the only one.  The switch is kept for its callers: it records the flag and returns the previous value, nothing else.  The
+ * gradients w.r.t. sample depths (V > 1), ray origins / directions and the source feature maps still accumulate with atomics. */
 int mvnerf_set_deterministic(int on);
 /* Bytes of scratch mvnerf_field_backward needs. */
 size_t mvnerf_field_backward_scratch_bytes(int B, int V, int R, int S);

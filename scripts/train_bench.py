@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--rays', type=int, default=4096)
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--size', type=int, default=64)
+ap.add_argument('--deterministic', action='store_true', help='weight gradients summed in a fixed order (mvnerf_set_deterministic)')
 ap.add_argument('--feature-grad', action='store_true', help='also time loss_and_grads with dL/d(combined_features)')
 args = ap.parse_args()
 dev = 'cuda:0'
@@ -25,7 +26,7 @@ r = sc['rays_o'].shape[1]
 y = torch.rand((1, r, 3), device=dev)
 m = MVVNeRFRenderer(r, r, n_views=1, near=sc['near'], far=sc['far'], device=dev)
 m.set_weights(sc['coarse'], sc['fine'])
-m.compile(learning_rate=1e-4)
+m.compile(learning_rate=1e-4, deterministic=args.deterministic)
 t = lambda k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev)
 inputs = tuple(t(k) for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'])
 feats, uc, uf = t('features'), t('u_coarse'), t('u_fine')
@@ -37,7 +38,7 @@ for _ in range(args.steps):
     out = m.train_step((inputs, y), combined_features=feats, u_coarse=uc, u_fine=uf)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
-print(f'train_step: {r} rays, {dt*1e3:.2f} ms/step = {r/dt:.0f} rays/s (fwd+bwd+Adam), loss {float(out["loss"]):.5f}')
+print(f'train_step{" (deterministic)" if args.deterministic else ""}: {r} rays, {dt*1e3:.2f} ms/step = {r/dt:.0f} rays/s (fwd+bwd+Adam), loss {float(out["loss"]):.5f}')
 
 if args.feature_grad:
     for _ in range(2):

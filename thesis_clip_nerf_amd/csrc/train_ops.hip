@@ -61,16 +61,36 @@ __device__ __forceinline__ void grad_out(float* dst, float v, bool store) {
     else atomicAdd(dst, v);
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ part, long part_stride, int n_parts, int count, float* __restrict__ dst) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    float s = 0.0f;
-    for (int w = 0; w < n_parts; ++w) s = s + part[(long)w * part_stride + i];
-    dst[i] = dst[i] + s;
+// dst[i] += sum over the workgroups' partials, in a fixed order (bit-identical from run to run): a 64 x 16 block takes 64 elements,
+// thread (x, y) adds the partials y, y + 16, y + 32, ... with four independent chains (the loads of a chain would otherwise wait for
+// each other: 512 serial loads per element took 250 us), the 16 partial sums are added in y order through LDS.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, long part_stride, int n_parts, int count,
+                                                               float* __restrict__ dst) {
+    __shared__ float sred[16][64];
+    const int x = threadIdx.x, y = threadIdx.y, i = blockIdx.x * 64 + x;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (i < count) {
+        int w = y;
+        for (; w + 48 < n_parts; w += 64) {
+            s0 = s0 + part[(long)w * part_stride + i];
+            s1 = s1 + part[(long)(w + 16) * part_stride + i];
+            s2 = s2 + part[(long)(w + 32) * part_stride + i];
+            s3 = s3 + part[(long)(w + 48) * part_stride + i];
+        }
+        for (; w < n_parts; w += 16) s0 = s0 + part[(long)w * part_stride + i];
+    }
+    sred[y][x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (y == 0 && i < count) {
+        float s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s = s + sred[q][x];
+        dst[i] = dst[i] + s;
+    }
 }
 
 hipError_t launch_reduce_partials(const float* part, long part_stride, int n_parts, int count, float* dst, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((count + 255) / 256), dim3(256), 0, st, part, part_stride, n_parts, count, dst);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((count + 63) / 64), dim3(64, 16), 0, st, part, part_stride, n_parts, count, dst);
     return hipGetLastError();
 }
 

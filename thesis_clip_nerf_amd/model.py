@@ -191,8 +191,8 @@ class MVVNeRFRenderer:
         (SURVEY.md Q9); set True to update the RenderReadout kernels as well.
         grad_sync: optional callable on the single flat gradient buffer (494 600 fp32), e.g.
         distributed.allreduce_mean_ for data-parallel training (one collective per step).
-        deterministic: True / False sets the library's weight-gradient reduction mode (ops.set_deterministic: fixed-order sums
-        instead of fp32 atomics, bit-identical gradients from run to run); None leaves it as it is."""
+        deterministic: kept for callers (ops.set_deterministic): the weight gradients are summed in a fixed order in any case.
+        """
         if deterministic is not None:
             ops.set_deterministic(deterministic)
         self._opt = dict(lr=learning_rate, b1=beta_1, b2=beta_2, eps=epsilon, clip=gradients_clip, step=0)

@@ -543,8 +543,9 @@ def field_backward(rays_o, rays_d, z, images, features, intrinsics, extrinsics_i
 
 
 def set_deterministic(on=True):
-    """mvnerf_set_deterministic: weight gradients summed in a fixed order (bit-identical from run to run) instead of by fp32
-    atomics; returns the previous mode."""
+    """mvnerf_set_deterministic.  Weight gradients are ALWAYS summed in a fixed order since round 2 (stored per-workgroup partials +
+    a parallel fixed-order reduction turned out faster than fp32 atomics); the call is kept for its callers, records the flag and
+    returns the previous value."""
     return bool(_lib.lib().mvnerf_set_deterministic(int(bool(on))))
 
 
