@@ -278,13 +278,16 @@ int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float*
                           const float* net_keras, const float* bwd_streams, const float* stash, const float* rgbs,
                           const float* d_rgbs, int B, int V, int R, int S, int H, int W, void* scratch, float* grad,
                           float* d_z, float* d_features, mvnerf_stream_t stream);
-/* mvnerf_field_backward with the forward's texel table of the SAME net (mvnerf_project_texels; optional, may be NULL): when it
- * is given and d_features is NULL, the gradient through the sample positions (d_z) takes the feature rows' part from four
- * table rows per sample instead of recomputing W0 . g0 over the 256 feature channels (same result up to fp32 rounding).
+/* mvnerf_field_backward with the forward's texel table of the SAME net (mvnerf_project_texels; optional, may be NULL).  With it the
+ * gradient through the sample positions (d_z) takes the feature rows' part from four table rows per sample instead of recomputing
+ * W0 . g0 over the 256 feature channels (same result up to fp32 rounding).  texel_grad (optional scratch, (B,V,H,W,128) floats,
+ * needs texel_table): when d_features is wanted, the samples' layer-0 cotangents are scattered onto this 128-channel table gradient
+ * and W0 is applied once per texel (dL/df[texel] = W0[123:379] . dL/dT[texel]) - a third of the atomics of the direct scatter and
+ * no 379 x 128 product per sample; without it d_features takes the direct path.
  * Reference: the same tape of MVVNeRFRenderer.train_step (model_v0.py:186-197); the table is this library's re-association of
  * layers.py:361-366 (see mvnerf_project_texels). */
 int mvnerf_field_backward_table(const float* rays_o, const float* rays_d, const float* z, const float* images,
-                                const float* features, const float* texel_table, const float* intrinsics,
+                                const float* features, const float* texel_table, float* texel_grad, const float* intrinsics,
                                 const float* extrinsics_inv, const float* net_keras, const float* bwd_streams, const float* stash,
                                 const float* rgbs, const float* d_rgbs, int B, int V, int R, int S, int H, int W, void* scratch,
                                 float* grad, float* d_z, float* d_features, mvnerf_stream_t stream);

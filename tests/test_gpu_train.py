@@ -245,10 +245,13 @@ def test_device_resident_generator_matches_host_generator():
     assert np.isfinite(float(out['loss']))
 
 
-@pytest.mark.parametrize('batch,views,stop', [(1, 1, True), (2, 2, False)])
-def test_feature_map_gradient_matches_torch_oracle(batch, views, stop):
-    """dL/d(combined_features): the cotangent handed back to an upstream encoder (scatter of the layer-0 input gradient to
-    the four taps), both field passes, with and without the path through the importance samples."""
+@pytest.mark.parametrize('batch,views,stop,table', [(1, 1, True, True), (2, 2, False, True), (1, 1, True, False), (2, 2, False, False)])
+def test_feature_map_gradient_matches_torch_oracle(batch, views, stop, table, monkeypatch):
+    """dL/d(combined_features): the cotangent handed back to an upstream encoder, both field passes, with and without the path
+    through the importance samples.  table=True: through the texel table (g0 scattered onto the 128-channel table gradient, W0 applied
+    once per texel: texel_scatter_kernel + texel_grad_to_features_kernel); table=False: the direct scatter of the layer-0 input
+    gradient to the four taps (field_dz_kernel<false>)."""
+    monkeypatch.setattr(ops, 'texel_table_pays', lambda *a: table)
     sc = make_scene(seed=70 + batch, batch=batch, n_views=views, height=12, width=16, n_rays=32, bias_scale=0.05)
     y = np.random.default_rng(3).random((batch, 32, 3)).astype(np.float32)
     ref = T.train_loss_and_grads(sc['coarse'], sc['fine'], y, sc, dtype=torch.float64, stop_fine_z=stop, feature_grad=True)

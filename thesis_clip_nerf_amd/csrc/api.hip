@@ -466,17 +466,19 @@ int mvnerf_field_backward(const float* rays_o, const float* rays_d, const float*
                           const float* net_keras, const float* bwd_streams, const float* stash, const float* rgbs,
                           const float* d_rgbs, int B, int V, int R, int S, int H, int W, void* scratch, float* grad,
                           float* d_z, float* d_features, mvnerf_stream_t stream) {
-    return mvnerf_field_backward_table(rays_o, rays_d, z, images, features, nullptr, intrinsics, extrinsics_inv, net_keras, bwd_streams,
-                                       stash, rgbs, d_rgbs, B, V, R, S, H, W, scratch, grad, d_z, d_features, stream);
+    return mvnerf_field_backward_table(rays_o, rays_d, z, images, features, nullptr, nullptr, intrinsics, extrinsics_inv, net_keras,
+                                       bwd_streams, stash, rgbs, d_rgbs, B, V, R, S, H, W, scratch, grad, d_z, d_features, stream);
 }
 
 int mvnerf_field_backward_table(const float* rays_o, const float* rays_d, const float* z, const float* images,
-                                const float* features, const float* texel_table, const float* intrinsics,
+                                const float* features, const float* texel_table, float* texel_grad, const float* intrinsics,
                                 const float* extrinsics_inv, const float* net_keras, const float* bwd_streams, const float* stash,
                                 const float* rgbs, const float* d_rgbs, int B, int V, int R, int S, int H, int W, void* scratch,
                                 float* grad, float* d_z, float* d_features, mvnerf_stream_t stream) {
     using namespace mvnerf;
-    if (texel_table && !aligned16(texel_table)) return fail(MVNERF_E_ALIGN, "mvnerf_field_backward: texel_table must be 16-byte aligned");
+    if ((texel_table && !aligned16(texel_table)) || (texel_grad && !aligned16(texel_grad)))
+        return fail(MVNERF_E_ALIGN, "mvnerf_field_backward: texel_table, texel_grad must be 16-byte aligned");
+    if (texel_grad && !texel_table) return fail(MVNERF_E_ARG, "mvnerf_field_backward: texel_grad needs texel_table");
     if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !net_keras || !bwd_streams ||
         !stash || !rgbs || !d_rgbs || !scratch || !grad)
         return fail(MVNERF_E_ARG, "mvnerf_field_backward: null pointer");
@@ -528,8 +530,17 @@ int mvnerf_field_backward_table(const float* rays_o, const float* rays_d, const 
     p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W; p.total = total; p.n_tiles = n_tiles;
     p.texel_table = texel_table;                           // only the sample-position gradient uses it (launch_field_dz)
     MV_TRY(launch_dw0(p, buf[g], grad + kKerasW0, grad + kKerasB0, kBwdMaxWGs, part, st));
-    if (d_z || d_features)
-        MV_TRY(launch_field_dz(p, buf[g], bwd_streams + (size_t)12 * kHiddenWFloats, d_z, nullptr, nullptr, d_features, st));
+    // d_features through the texel table (texel_grad given): the samples' g0 is scattered onto the 128-channel table gradient and W0 is
+    // applied once per texel afterwards; the sample-position gradient then takes the table path as well
+    const bool via_table = d_features && texel_table && texel_grad;
+    if (via_table) {
+        const long n_texels = (long)B * V * H * W;
+        MV_TRY(hipMemsetAsync(texel_grad, 0, (size_t)n_texels * 128 * sizeof(float), st));
+        MV_TRY(launch_texel_scatter(p, buf[g], texel_grad, st));
+        MV_TRY(launch_texel_grad_to_features(texel_grad, net_keras + kKerasW0 + 123 * kHidden, n_texels, d_features, st));
+    }
+    if (d_z || (d_features && !via_table))
+        MV_TRY(launch_field_dz(p, buf[g], bwd_streams + (size_t)12 * kHiddenWFloats, d_z, nullptr, nullptr, via_table ? nullptr : d_features, st));
 #undef MV_TRY
     return 0;
 }

@@ -83,6 +83,8 @@ hipError_t launch_finish_view(const float* rgb, const float* depth, long n, floa
 hipError_t launch_pack_bwd_streams(const float* net_keras, float* dst, hipStream_t st);
 hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, float* d_o,
                            float* d_d, float* d_features, hipStream_t st);
+hipError_t launch_texel_scatter(const FieldParams& p, const float* g0_tl, float* texel_grad, hipStream_t st);
+hipError_t launch_texel_grad_to_features(const float* texel_grad, const float* w0_feat, long n_texels, float* d_features, hipStream_t st);
 hipError_t launch_rows_to_tl(const float* rows, long n_rows, long n_tiles, int accumulate, float* out_tl, hipStream_t st);
 hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int g_feats, long n_tiles, float* dW, int ldn,
                           int n_valid, float* db, int max_wgs, float* part, hipStream_t st);

@@ -1649,6 +1649,114 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
     if (d_z && valid && h == 0) atomicAdd(d_z + g, dzv);    // the V views of a sample add up
 }
 
+// ---- gradient w.r.t. the source feature maps through the texel table (mvnerf_field_backward_table with texel_grad) ---------------
+// First half: dL/dT[texel][n] += (bilinear weight) x g0[sample][n] on the sample's four taps - 128 table channels instead of 256 feature
+// channels per tap, and no W0 . g0 product per sample.  One wave per view tile, lane = channel pair (n, n + 64): the lane holds its two
+// rows of the g0 tile (32 samples each), the samples' tap texel and weights are wave-uniform (readlane), so an atomic instruction adds 64
+// consecutive floats of ONE table row (with lane = sample the 32 samples of a ray pile onto the same few addresses: 40 ms per step),
+// and consecutive samples that fall into the same texel are summed in registers first.
+__global__ __launch_bounds__(256) void texel_scatter_kernel(FieldParams p, const float* __restrict__ g0_tl, float* __restrict__ texel_grad) {
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // view tile
+    if (tile >= p.n_tiles * p.V) return;
+    // geometry of sample j (both half-waves compute it; lanes 0..31 are read)
+    const bool valid = tile * 32 + j < p.total * p.V;
+    const ViewRow vr = view_row(p, tile * 32 + j);
+    const int ray = vr.ray, b = vr.bv;
+    const float* E = p.einv + 16 * b;
+    const float zz = p.z ? p.z[vr.g] : 0.0f;
+    const float dx = p.rays_d[3 * ray], dy = p.rays_d[3 * ray + 1], dz = p.rays_d[3 * ray + 2];
+    const float wx = p.rays_o[3 * ray] + zz * dx, wy = p.rays_o[3 * ray + 1] + zz * dy, wz = p.rays_o[3 * ray + 2] + zz * dz;
+    float cam[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cam[r] = row_dot4(E, r, wx, wy, wz, 1.0f);
+    float px, py;
+    pixel_from_cam(p.k4 + 16 * b, cam, &px, &py);
+    const Taps tp = bilinear_taps(px, py, p.H, p.W);
+    const int tl = valid ? (b * p.H + tp.y0) * p.W + tp.x0 : -1;
+    // this lane's two channel rows of the tile: features lane and lane + 64, 32 samples each
+    f32x4 ga[8], gb[8];
+    {
+        const f32x4* ra = reinterpret_cast<const f32x4*>(g0_tl + tl_index(tile, 128, lane, 0));
+        const f32x4* rb = reinterpret_cast<const f32x4*>(g0_tl + tl_index(tile, 128, lane + 64, 0));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            ga[q] = ra[q];
+            gb[q] = rb[q];
+        }
+    }
+    float a0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, a1[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // taps (0,0), (0,1), (1,0), (1,1) of channels lane / lane + 64
+    int cur = -1;
+    auto flush = [&]() {
+        if (cur >= 0) {
+            float* G = texel_grad + 128 * (long)cur + lane;
+            const long rs = 128 * (long)p.W;
+            atomicAdd(G, a0[0]);
+            atomicAdd(G + 64, a1[0]);
+            atomicAdd(G + 128, a0[1]);
+            atomicAdd(G + 192, a1[1]);
+            atomicAdd(G + rs, a0[2]);
+            atomicAdd(G + rs + 64, a1[2]);
+            atomicAdd(G + rs + 128, a0[3]);
+            atomicAdd(G + rs + 192, a1[3]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a0[t] = 0.0f;
+            a1[t] = 0.0f;
+        }
+    };
+#pragma unroll
+    for (int sidx = 0; sidx < 32; ++sidx) {
+        const int tls = __builtin_amdgcn_readlane(tl, sidx);
+        if (tls < 0) continue;                               // padded sample (wave-uniform)
+        const float axs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tp.ax), sidx));
+        const float ays = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tp.ay), sidx));
+        if (tls != cur) {
+            flush();
+            cur = tls;
+        }
+        const float va = ga[sidx >> 2][sidx & 3], vb = gb[sidx >> 2][sidx & 3];
+        const float w[4] = {(1.0f - axs) * (1.0f - ays), axs * (1.0f - ays), (1.0f - axs) * ays, axs * ays};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a0[t] = fmaf(va, w[t], a0[t]);
+            a1[t] = fmaf(vb, w[t], a1[t]);
+        }
+    }
+    flush();
+}
+
+// Second half: dL/df[texel][c] += sum_n W0[123 + c][n] dL/dT[texel][n].  One thread per (texel, channel); W0's 128 KiB stay in cache.
+__global__ __launch_bounds__(256) void texel_grad_to_features_kernel(const float* __restrict__ texel_grad, const float* __restrict__ w0_feat,
+                                                                     long n_texels, float* __restrict__ d_features) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_texels * 256) return;
+    const long t = idx >> 8;
+    const int c = (int)(idx & 255);
+    const f32x4* g = reinterpret_cast<const f32x4*>(texel_grad + 128 * t);
+    const f32x4* wrow = reinterpret_cast<const f32x4*>(w0_feat + (long)c * kHidden);
+    float s = 0.0f;
+#pragma unroll 8
+    for (int q = 0; q < 32; ++q) {
+        const f32x4 gv = g[q], wv = wrow[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s = fmaf(gv[e], wv[e], s);
+    }
+    d_features[idx] = d_features[idx] + s;
+}
+
+hipError_t launch_texel_scatter(const FieldParams& p, const float* g0_tl, float* texel_grad, hipStream_t st) {
+    hipLaunchKernelGGL(texel_scatter_kernel, dim3((unsigned)((p.n_tiles * p.V + 3) / 4)), dim3(256), 0, st, p, g0_tl, texel_grad);
+    return hipGetLastError();
+}
+
+hipError_t launch_texel_grad_to_features(const float* texel_grad, const float* w0_feat, long n_texels, float* d_features, hipStream_t st) {
+    hipLaunchKernelGGL(texel_grad_to_features_kernel, dim3((unsigned)((n_texels * 256 + 255) / 256)), dim3(256), 0, st, texel_grad, w0_feat,
+                       n_texels, d_features);
+    return hipGetLastError();
+}
+
 hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, float* d_o,
                            float* d_d, float* d_features, hipStream_t st) {
     const unsigned wgs = (unsigned)((p.n_tiles * p.V + 3) / 4);

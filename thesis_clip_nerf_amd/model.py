@@ -258,13 +258,19 @@ class MVVNeRFRenderer:
         else:
             d_rgbs_f, d_z_all = ops.composite_bwd(z_all, rgbs_f, d_fine, return_dz=True)
         d_feat = torch.zeros_like(feats) if return_d_features else None
+        tgrad = None
+        if return_d_features and tab_f is not None:              # scratch for the feature-map gradient through the texel table
+            if tb.get('texel_grad') is None or tuple(tb['texel_grad'].shape) != tuple(tab_f.shape):
+                tb['texel_grad'] = torch.empty_like(tab_f)
+            tgrad = tb['texel_grad']
         tb['scratch'] = ops.field_backward(rays_o, rays_d, z_all, *geo, self.fine_net, self._packed_bwd[1], tb['stash_f'],
-                                           rgbs_f, d_rgbs_f, gf, tb.get('scratch'), d_z=d_z_all, d_features=d_feat, texel_table=tab_f)
+                                           rgbs_f, d_rgbs_f, gf, tb.get('scratch'), d_z=d_z_all, d_features=d_feat, texel_table=tab_f,
+                                           texel_grad=tgrad)
         if not stop_fine_z:
             d_w = ops.resample_bwd(z, w, self._dev(u_fine), rank, d_z_all, self.q7_mode)
         d_rgbs_c = ops.composite_bwd(z, rgbs_c, d_rgb, d_weights=d_w)
         tb['scratch'] = ops.field_backward(rays_o, rays_d, z, *geo, self.coarse_net, self._packed_bwd[0], tb['stash_c'],
-                                           rgbs_c, d_rgbs_c, gc, tb['scratch'], d_features=d_feat)
+                                           rgbs_c, d_rgbs_c, gc, tb['scratch'], d_features=d_feat, texel_table=tab_c, texel_grad=tgrad)
         if return_d_features:
             return loss, self._grad, (rgb, depth, fine_rgb, fine_depth), d_feat
         return loss, self._grad, (rgb, depth, fine_rgb, fine_depth)

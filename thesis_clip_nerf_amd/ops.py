@@ -512,11 +512,12 @@ def composite_bwd(z, rgbs, d_rgb, d_depth=None, d_weights=None, return_dz=False)
 
 
 def field_backward(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, net_keras, bwd_streams, stash, rgbs,
-                   d_rgbs, grad, scratch=None, d_z=None, d_features=None, texel_table=None):
+                   d_rgbs, grad, scratch=None, d_z=None, d_features=None, texel_table=None, texel_grad=None):
     """Accumulate dL/d(net variables) of one field_eval_stash call into `grad` (247300 floats, Keras order);
     d_z (optional, (B,R,S)) is incremented by the gradient through the sample positions, d_features (optional,
     (B,V,H,W,256)) by the gradient w.r.t. the source feature maps.  texel_table (optional): project_texels of the same
-    net; used for the feature rows' part of d_z when d_features is not wanted (mvnerf_field_backward_table)."""
+    net; used for the feature rows' part of d_z, and - with the scratch texel_grad (B,V,H,W,128) - for d_features (the cotangents are
+    scattered onto the 128-channel table gradient and W0 is applied once per texel; mvnerf_field_backward_table)."""
     b, r, s = z.shape
     _, v, h, w, _ = images.shape
     _chk(net_keras, 'net_keras', shape=(NET_PARAMS,))
@@ -533,9 +534,11 @@ def field_backward(rays_o, rays_d, z, images, features, intrinsics, extrinsics_i
         scratch = torch.empty(need, dtype=torch.uint8, device=z.device)
     if texel_table is not None:
         _chk(texel_table, 'texel_table', shape=(b, v, h, w, 128))
+    if texel_grad is not None:
+        _chk(texel_grad, 'texel_grad', shape=(b, v, h, w, 128))
     with torch.cuda.device(z.device):
         rc = _lib.lib().mvnerf_field_backward_table(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(texel_table),
-                                                    _p(intrinsics), _p(extrinsics_inv), _p(net_keras), _p(bwd_streams), _p(stash),
+                                                    _p(texel_grad), _p(intrinsics), _p(extrinsics_inv), _p(net_keras), _p(bwd_streams), _p(stash),
                                                     _p(rgbs), _p(d_rgbs), b, v, r, s, h, w, _p(scratch), _p(grad), _p(d_z),
                                                     _p(d_features), _stream(z))
     _lib.check(rc, 'field_backward')
