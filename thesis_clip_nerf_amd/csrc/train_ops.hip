@@ -1649,6 +1649,175 @@ __global__ __launch_bounds__(256, 1) void field_dz_kernel(FieldParams p, const f
     if (d_z && valid && h == 0) atomicAdd(d_z + g, dzv);    // the V views of a sample add up
 }
 
+// ---- the training form of the sample-depth gradient with the texel table: d_z only --------------------------------------------------
+// Of W0 . g0 only the rows PE(cam xyz) (0..59) and rgb (120..122) are needed: the first two 32-row blocks of slab 0 go through the MFMA
+// (128 instead of 256 fp32 MFMAs per tile, 32 instead of 64 accumulator registers: two waves per SIMD), the three rgb rows are 3 x 64
+// fused multiply-adds per lane against W0 rows staged in LDS in accumulator order, the feature rows come from the table as in
+// field_dz_kernel<true>.  358 -> see DESIGN.md section 8.
+__global__ __launch_bounds__(256, 2) void field_dz_table_kernel(FieldParams p, const float* __restrict__ g0_tl,
+                                                                const float* __restrict__ w0t_slab0, const float* __restrict__ w0_rgb,
+                                                                float* __restrict__ d_z) {
+    __shared__ __attribute__((aligned(16))) float s_rgb[3][2][64];
+    for (int t = threadIdx.x; t < 384; t += 256) {
+        const int c = t >> 7, pos = t & 127, hh = pos >> 6, q = pos & 63;
+        s_rgb[c][hh][q] = w0_rgb[c * kHidden + 32 * (q >> 4) + acc_row(q & 15, hh)];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile = (long)blockIdx.x * 4 + wave;          // view tile
+    if (tile >= p.n_tiles * p.V) return;
+    const bool valid = tile * 32 + j < p.total * p.V;
+    const ViewRow vr = view_row(p, tile * 32 + j);
+    const long g = vr.g;
+    const int ray = vr.ray, b = vr.bv;                      // `b` indexes the (B*V) cameras / grids below
+    const float* E = p.einv + 16 * b;
+    const float* K = p.k4 + 16 * b;
+    const float zz = p.z[g];
+    const float dx = p.rays_d[3 * ray], dy = p.rays_d[3 * ray + 1], dz = p.rays_d[3 * ray + 2];
+    const float wx = p.rays_o[3 * ray] + zz * dx, wy = p.rays_o[3 * ray + 1] + zz * dy, wz = p.rays_o[3 * ray + 2] + zz * dz;
+    float cam[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cam[r] = row_dot4(E, r, wx, wy, wz, 1.0f);
+    const float q0 = row_dot4(K, 0, cam[0], cam[1], cam[2], cam[3]);
+    const float q1 = row_dot4(K, 1, cam[0], cam[1], cam[2], cam[3]);
+    const float q2 = row_dot4(K, 2, cam[0], cam[1], cam[2], cam[3]);
+    const float den = fmaxf(q2, 1e-8f);
+    const float pxr = q0 / den, pyr = q1 / den;
+    const float px = fminf(fmaxf(pxr, -1e6f), 1e6f), py = fminf(fmaxf(pyr, -1e6f), 1e6f);
+    const Taps tp = bilinear_taps(px, py, p.H, p.W);
+    const int tl = (b * p.H + tp.y0) * p.W + tp.x0;
+    const float ux = px - fminf(fmaxf(0.0f, floorf(px)), (float)(p.W - 2));      // unclamped lerp factors
+    const float uy = py - fminf(fmaxf(0.0f, floorf(py)), (float)(p.H - 2));
+
+    f32x16 bin[4];                                          // g0 of sample j in accumulator order: bin[kb][r] = g0[32 kb + acc_row(r, h)]
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bin[kb][r] = g0_tl[tl_index(tile, 128, 32 * kb + acc_row(r, h), j)];
+
+    // ---- rows 0..63 of W0 . g0: chunks (grp, nb = 0, 1) of the transposed slab-0 stream, requested one group ahead ----
+    f32x16 acc[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+    {
+        const f32x4* ws = reinterpret_cast<const f32x4*>(w0t_slab0) + lane;
+        f32x4 c0 = ws[0], c1 = ws[64];
+#pragma unroll
+        for (int grp = 0; grp < 16; ++grp) {
+            f32x4 n0 = c0, n1 = c1;
+            if (grp < 15) {
+                n0 = ws[256 * (grp + 1)];
+                n1 = ws[256 * (grp + 1) + 64];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float bv = bin[grp >> 2][4 * (grp & 3) + e];
+                acc[0] = mfma(c0[e], bv, acc[0]);
+                acc[1] = mfma(c1[e], bv, acc[1]);
+            }
+            c0 = n0;
+            c1 = n1;
+        }
+    }
+    float dcam[3] = {0.0f, 0.0f, 0.0f};
+    float dax = 0.0f, day = 0.0f;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const int row = 32 * nb + acc_row(r, h);        // PE(cam xyz) rows come as (sin, cos) pairs in adjacent registers
+            if (row < 60) {
+                const int d = row / 20, oct = (row % 20) >> 1;
+                const float f = 3.14159274101257324f * (float)(1 << oct);
+                float sv, cv;
+                sincos_f32(cam[d] * f, &sv, &cv);
+                const float contrib = f * (acc[nb][r] * cv - acc[nb][r + 1] * sv);
+                if (d == 0) dcam[0] += contrib;
+                else if (d == 1) dcam[1] += contrib;
+                else dcam[2] += contrib;
+            }
+        }
+    // ---- rgb rows 120..122: this lane's half of the 128-term sums, both halves added, used by the lower half-wave ----
+    {
+        float v3[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f32x4* wr = reinterpret_cast<const f32x4*>(&s_rgb[c][h][0]);
+            float s = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w4 = wr[4 * kb + q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s = fmaf(w4[e], bin[kb][4 * q + e], s);
+                }
+            v3[c] = s + __shfl_xor(s, 32);
+        }
+        if (h == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* im = p.images + 3 * (long)tl + c;
+                const float a = im[0] * 2.0f - 1.0f, bq = im[3] * 2.0f - 1.0f, cq = im[3 * p.W] * 2.0f - 1.0f, dq = im[3 * p.W + 3] * 2.0f - 1.0f;
+                dax += v3[c] * ((1.0f - tp.ay) * (bq - a) + tp.ay * (dq - cq));
+                day += v3[c] * ((cq - a) + tp.ax * ((dq - cq) - (bq - a)));
+            }
+        }
+    }
+    // ---- feature rows through the table: this lane's half (64 h .., accumulator order) of the four table rows ----
+    {
+        const f32x4* T = reinterpret_cast<const f32x4*>(p.texel_table) + 32 * (long)tl + 16 * h;
+        const long rowstep = 32 * (long)p.W;
+        const float one_m_ay = 1.0f - tp.ay;
+        float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            f32x4 trow[4][4];                               // one output block at a time: 16 loads in flight
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                trow[q][0] = T[4 * nb + q];
+                trow[q][1] = T[32 + 4 * nb + q];
+                trow[q][2] = T[rowstep + 4 * nb + q];
+                trow[q][3] = T[rowstep + 32 + 4 * nb + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float gv = bin[nb][4 * q + c];
+                    const float dt = trow[q][1][c] - trow[q][0][c], db = trow[q][3][c] - trow[q][2][c];
+                    pa += gv * (one_m_ay * dt + tp.ay * db);
+                    pb += gv * ((trow[q][2][c] - trow[q][0][c]) + tp.ax * (db - dt));
+                }
+        }
+        dax += pa;
+        day += pb;
+    }
+    // combine the two half-waves
+#pragma unroll
+    for (int d = 0; d < 3; ++d) dcam[d] += __shfl_xor(dcam[d], 32);
+    dax += __shfl_xor(dax, 32);
+    day += __shfl_xor(day, 32);
+    // clamps (torch.clamp semantics: gradient passes inside the closed range)
+    const float dpx = (ux >= 0.0f && ux <= 1.0f && pxr >= -1e6f && pxr <= 1e6f) ? dax : 0.0f;
+    const float dpy = (uy >= 0.0f && uy <= 1.0f && pyr >= -1e6f && pyr <= 1e6f) ? day : 0.0f;
+    const float dq0 = dpx / den, dq1 = dpy / den;
+    const float dq2 = q2 >= 1e-8f ? -(dpx * q0 + dpy * q1) / (den * den) : 0.0f;
+    float dc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dc[c] = K[c] * dq0 + K[4 + c] * dq1 + K[8 + c] * dq2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dc[c] += dcam[c];
+    float dzv = 0.0f;
+    const float dirv[3] = {dx, dy, dz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dzv += (E[a] * dc[0] + E[4 + a] * dc[1] + E[8 + a] * dc[2] + E[12 + a] * dc[3]) * dirv[a];
+    if (valid && h == 0) atomicAdd(d_z + g, dzv);           // the V views of a sample add up
+}
+
 // ---- gradient w.r.t. the source feature maps through the texel table (mvnerf_field_backward_table with texel_grad) ---------------
 // First half: dL/dT[texel][n] += (bilinear weight) x g0[sample][n] on the sample's four taps - 128 table channels instead of 256 feature
 // channels per tap, and no W0 . g0 product per sample.  One wave per view tile, lane = channel pair (n, n + 64): the lane holds its two
@@ -1760,6 +1929,10 @@ hipError_t launch_texel_grad_to_features(const float* texel_grad, const float* w
 hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, float* d_o,
                            float* d_d, float* d_features, hipStream_t st) {
     const unsigned wgs = (unsigned)((p.n_tiles * p.V + 3) / 4);
+    if (p.texel_table && !d_features && d_z && !d_o && !d_d && p.net) {   // training: only dL/dz, rows 0..63 + rgb of W0 . g0
+        hipLaunchKernelGGL(field_dz_table_kernel, dim3(wgs), dim3(256), 0, st, p, g0_tl, w0t_streams, p.net + kKerasW0 + 120 * kHidden, d_z);
+        return hipGetLastError();
+    }
     if (p.texel_table && !d_features) {                   // feature rows through the forward's texel table, no LDS
         hipLaunchKernelGGL(field_dz_kernel<true>, dim3(wgs), dim3(256), 0, st, p, g0_tl, w0t_streams, d_z, d_o, d_d, d_features);
         return hipGetLastError();
