@@ -72,6 +72,12 @@ def test_argument_validation_of_table_and_query_entry_points():
     v_tail = [one, one, one, None]                                     # scratch, d_points, d_dirs, stream
     assert lib.mvnerf_query_vjp(*([one] * 9), 1, 2, 40, 8, 8, *v_tail) == -2                      # V > 1 needs N % 32 == 0
     assert lib.mvnerf_query_vjp(*([one] * 8), odd, 1, 1, 40, 8, 8, *v_tail) == -3                 # misaligned g_acts
+    # training backward with the texel table: the table gradient scratch needs the table; both are checked for alignment
+    fb = lambda table, tgrad: lib.mvnerf_field_backward_table(one, one, one, one, one, table, tgrad, one, one, one, one, one, one, one,
+                                                              1, 1, 4, 64, 8, 8, one, one, None, one, None)
+    assert fb(None, one) == -1 and b'texel_grad needs texel_table' in lib.mvnerf_last_error()
+    assert fb(odd, None) == -3
+    assert fb(one, odd) == -3
     # bf16 entry point: optional table / fused activations are checked for alignment
     b_tail = [one, None, None, odd, one, None]                         # rgbs, tap_idx, embedding, acts_fused, workspace, stream
     assert lib.mvnerf_field_eval_bf16(one, one, one, one, one, None, one, one, one, one, 1, 1, 4, 64, 8, 8, *b_tail) == -3
