@@ -1855,25 +1855,20 @@ __global__ __launch_bounds__(256) void texel_scatter_kernel(FieldParams p, const
         }
     }
     float a0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, a1[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // taps (0,0), (0,1), (1,0), (1,1) of channels lane / lane + 64
-    int cur = -1;
-    auto flush = [&]() {
-        if (cur >= 0) {
-            float* G = texel_grad + 128 * (long)cur + lane;
-            const long rs = 128 * (long)p.W;
-            atomicAdd(G, a0[0]);
-            atomicAdd(G + 64, a1[0]);
-            atomicAdd(G + 128, a0[1]);
-            atomicAdd(G + 192, a1[1]);
-            atomicAdd(G + rs, a0[2]);
-            atomicAdd(G + rs + 64, a1[2]);
-            atomicAdd(G + rs + 128, a0[3]);
-            atomicAdd(G + rs + 192, a1[3]);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a0[t] = 0.0f;
-            a1[t] = 0.0f;
-        }
+    int cur = -1;                                            // top-left texel of the 2 x 2 window the accumulators belong to
+    const long rs = 128 * (long)p.W;
+    auto flush_tap = [&](int t) {                            // t = 2 * dy + dx
+        float* G = texel_grad + 128 * (long)cur + lane + (t & 1) * 128 + (t >> 1) * rs;
+        atomicAdd(G, a0[t]);
+        atomicAdd(G + 64, a1[t]);
+        a0[t] = 0.0f;
+        a1[t] = 0.0f;
+    };
+    auto move_tap = [&](int to, int from) {
+        a0[to] = a0[from];
+        a1[to] = a1[from];
+        a0[from] = 0.0f;
+        a1[from] = 0.0f;
     };
 #pragma unroll
     for (int sidx = 0; sidx < 32; ++sidx) {
@@ -1882,7 +1877,34 @@ __global__ __launch_bounds__(256) void texel_scatter_kernel(FieldParams p, const
         const float axs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tp.ax), sidx));
         const float ays = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tp.ay), sidx));
         if (tls != cur) {
-            flush();
+            // the window moved: a sample's neighbours along the ray mostly sit one texel to the side, and the two taps the windows share
+            // keep their sums in registers (all branches are wave-uniform)
+            const int delta = tls - cur;
+            if (cur < 0) {
+            } else if (delta == 1) {
+                flush_tap(0);
+                flush_tap(2);
+                move_tap(0, 1);
+                move_tap(2, 3);
+            } else if (delta == -1) {
+                flush_tap(1);
+                flush_tap(3);
+                move_tap(1, 0);
+                move_tap(3, 2);
+            } else if (delta == p.W) {
+                flush_tap(0);
+                flush_tap(1);
+                move_tap(0, 2);
+                move_tap(1, 3);
+            } else if (delta == -p.W) {
+                flush_tap(2);
+                flush_tap(3);
+                move_tap(2, 0);
+                move_tap(3, 1);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) flush_tap(t);
+            }
             cur = tls;
         }
         const float va = ga[sidx >> 2][sidx & 3], vb = gb[sidx >> 2][sidx & 3];
@@ -1893,7 +1915,10 @@ __global__ __launch_bounds__(256) void texel_scatter_kernel(FieldParams p, const
             a1[t] = fmaf(vb, w[t], a1[t]);
         }
     }
-    flush();
+    if (cur >= 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) flush_tap(t);
+    }
 }
 
 // Second half: dL/df[texel][c] += sum_n W0[123 + c][n] dL/dT[texel][n].  One thread per (texel, channel); W0's 128 KiB stay in cache.
