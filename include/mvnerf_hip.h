@@ -292,6 +292,21 @@ int mvnerf_field_backward_table(const float* rays_o, const float* rays_d, const 
                                 const float* rgbs, const float* d_rgbs, int B, int V, int R, int S, int H, int W, void* scratch,
                                 float* grad, float* d_z, float* d_features, mvnerf_stream_t stream);
 
+/* c (M,N) = a (M,K) . bt (N,K)^T in fp32 (fp32 MFMA, one wave per 32 x 64 output block; small outputs with a long K are split along K,
+ * the splits' partials go to `scratch` and are added in split order: no atomics, bit-identical from run to run).
+ * For the GraspReadout's Dense layers (delta_ngf/layers.py:8-42 as used by lmvnerf/model_v4.py:290-322), their input / weight gradients
+ * and the derivatives of those - skinny products (64 x 128 outputs over K = 64 512 rows, 1536 x 128 over K = 2688) on which the library
+ * GEMM runs a handful of workgroups.  M % 32 == 0, N % 64 == 0, K % 8 == 0, 16-byte aligned row-major buffers;
+ * scratch: mvnerf_gemm_nt_scratch_bytes(M,N,K) bytes (0 for shapes that are not split: NULL allowed). */
+size_t mvnerf_gemm_nt_scratch_bytes(int M, int N, int K);
+int mvnerf_gemm_nt(const float* a, const float* bt, float* c, int M, int N, int K, void* scratch, mvnerf_stream_t stream);
+
+/* c (N,K) = g (M,N)^T . a (M,K): the weight gradient of a Dense layer with both operands as they lie (rows = the M samples that are
+ * contracted), same kernel family and determinism as mvnerf_gemm_nt.  M % 8 == 0, N % 32 == 0, K % 64 == 0;
+ * scratch: mvnerf_gemm_tn_scratch_bytes(M,N,K) bytes. */
+size_t mvnerf_gemm_tn_scratch_bytes(int M, int N, int K);
+int mvnerf_gemm_tn(const float* g, const float* a, float* c, int M, int N, int K, void* scratch, mvnerf_stream_t stream);
+
 /* ---- The trunk as a differentiable field on arbitrary query points. ----
  * Reference consumer: LanguageNeRF._call (lmvnerf/model_v4.py:208-265) evaluates fine_embedding on
  * camera_points / camera_directions derived from grasp poses and keeps outputs[4:] = (view mean, u1, u2, u3)

@@ -66,6 +66,10 @@ SIGNATURES = {
     'mvnerf_mse_grad': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     'mvnerf_composite_bwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'mvnerf_field_backward': (c_int, [c_void_p] * 12 + [c_int] * 6 + [c_void_p] * 5),
+    'mvnerf_gemm_nt_scratch_bytes': (c_size_t, [c_int] * 3),
+    'mvnerf_gemm_tn_scratch_bytes': (c_size_t, [c_int] * 3),
+    'mvnerf_gemm_tn': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p] * 2),
+    'mvnerf_gemm_nt': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p] * 2),
     'mvnerf_field_backward_table': (c_int, [c_void_p] * 14 + [c_int] * 6 + [c_void_p] * 5),
     'mvnerf_adam_clip': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float,
                                  c_void_p, c_void_p]),

@@ -546,6 +546,44 @@ int mvnerf_field_backward_table(const float* rays_o, const float* rays_d, const 
     return 0;
 }
 
+static bool gemm_nt_shape_ok(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && M % 32 == 0 && N % 64 == 0 && K % 8 == 0; }
+
+size_t mvnerf_gemm_nt_scratch_bytes(int M, int N, int K) {
+    if (!gemm_nt_shape_ok(M, N, K)) return 0;
+    const int splits = mvnerf::gemm_nt_splits(M, N, K);
+    return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+}
+
+int mvnerf_gemm_nt(const float* a, const float* bt, float* c, int M, int N, int K, void* scratch, mvnerf_stream_t stream) {
+    if (!a || !bt || !c) return fail(MVNERF_E_ARG, "mvnerf_gemm_nt: null pointer");
+    if (!gemm_nt_shape_ok(M, N, K))
+        return fail(MVNERF_E_SHAPE, "mvnerf_gemm_nt: M=%d N=%d K=%d, needs M %% 32 == 0, N %% 64 == 0, K %% 8 == 0", M, N, K);
+    if (!aligned16(a) || !aligned16(bt) || !aligned16(c) || (scratch && !aligned16(scratch)))
+        return fail(MVNERF_E_ALIGN, "mvnerf_gemm_nt: a, bt, c, scratch must be 16-byte aligned");
+    if (mvnerf_gemm_nt_scratch_bytes(M, N, K) && !scratch) return fail(MVNERF_E_ARG, "mvnerf_gemm_nt: this shape needs scratch");
+    return hip_status(mvnerf::launch_gemm_nt_f32(a, bt, c, M, N, K, static_cast<float*>(scratch), static_cast<hipStream_t>(stream)),
+                      "mvnerf_gemm_nt");
+}
+
+static bool gemm_tn_shape_ok(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && M % 8 == 0 && N % 32 == 0 && K % 64 == 0; }
+
+size_t mvnerf_gemm_tn_scratch_bytes(int M, int N, int K) {
+    if (!gemm_tn_shape_ok(M, N, K)) return 0;
+    const int splits = mvnerf::gemm_tn_splits(M, N, K);
+    return splits > 1 ? (size_t)splits * N * K * sizeof(float) : 0;
+}
+
+int mvnerf_gemm_tn(const float* g, const float* a, float* c, int M, int N, int K, void* scratch, mvnerf_stream_t stream) {
+    if (!g || !a || !c) return fail(MVNERF_E_ARG, "mvnerf_gemm_tn: null pointer");
+    if (!gemm_tn_shape_ok(M, N, K))
+        return fail(MVNERF_E_SHAPE, "mvnerf_gemm_tn: M=%d N=%d K=%d, needs M %% 8 == 0, N %% 32 == 0, K %% 64 == 0", M, N, K);
+    if (!aligned16(g) || !aligned16(a) || !aligned16(c) || (scratch && !aligned16(scratch)))
+        return fail(MVNERF_E_ALIGN, "mvnerf_gemm_tn: g, a, c, scratch must be 16-byte aligned");
+    if (mvnerf_gemm_tn_scratch_bytes(M, N, K) && !scratch) return fail(MVNERF_E_ARG, "mvnerf_gemm_tn: this shape needs scratch");
+    return hip_status(mvnerf::launch_gemm_tn_f32(g, a, c, M, N, K, static_cast<float*>(scratch), static_cast<hipStream_t>(stream)),
+                      "mvnerf_gemm_tn");
+}
+
 // ---- the trunk as a differentiable field on query points --------------------------------------
 size_t mvnerf_query_workspace_bytes(int B, int V, int N) {
     if (B <= 0 || V <= 0 || N <= 0) return 0;

@@ -1,0 +1,180 @@
+// fp32 "NT" GEMM for the GraspReadout's wide Dense layers (delta_ngf/layers.py:8-42 via lmvnerf/model_v4.py: block_0 maps the
+// 42 x 64 = 2688 concatenated offset features of a grasp to 128 / 64 units).  LanguageNeRF's train_step evaluates that layer, its input
+// gradient, its weight gradient and their derivatives on M = B x n_points <= a few thousand rows: GEMMs of 1 GFLOP whose library
+// kernels run 36 workgroups (246 us) or 65 k threads of 16 x 16 tiles (589 us) on this shape (profiles/r02_language_step_trace.md).
+//
+//   C[M][N] = sum_k A[M][K] Bt[N][K]        (both operands K-contiguous: x @ W^T with torch's Linear weight layout)
+//
+// One wave per 32 x 64 block of C, v_mfma_f32_32x32x2_f32 with fp32 operands (the products and the accumulation are the library's),
+// a lane's 4 k-slots of 8 consecutive k are one float4 (k = k0 + 4h + e for MFMA e), operands straight from global memory (the
+// matrices are L2-resident).  Small outputs with a long K (the weight gradients: 64 x 128 outputs over K = B x n_points x 42 = 64 512
+// rows) are split along K over blockIdx.y; every split stores its partial and gemm_reduce_kernel adds them in split order - no
+// atomics, bit-identical from run to run.
+#include <hip/hip_runtime.h>
+
+#include "mvnerf_kernels.h"
+#include "mvnerf_mfma.h"
+
+namespace mvnerf {
+
+__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bt, float* __restrict__ C,
+                                                          int M, int N, int K, int splits) {
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int tiles_n = N / 64;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= (M / 32) * tiles_n) return;
+    const int tm = t / tiles_n, tn = t % tiles_n;
+    const f32x4* a = reinterpret_cast<const f32x4*>(A + (long)(32 * tm + i) * K) + h;
+    const f32x4* b0 = reinterpret_cast<const f32x4*>(Bt + (long)(64 * tn + i) * K) + h;
+    const f32x4* b1 = reinterpret_cast<const f32x4*>(Bt + (long)(64 * tn + 32 + i) * K) + h;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc0[r] = 0.0f;
+        acc1[r] = 0.0f;
+    }
+    const int steps = K / 8, split = (int)blockIdx.y;
+    const int s_begin = (int)((long)steps * split / splits), s_end = (int)((long)steps * (split + 1) / splits);
+    C += (long)split * M * N;                                // (splits > 1: C is the partial buffer)
+#pragma unroll 4
+    for (int s = s_begin; s < s_end; ++s) {
+        const f32x4 a4 = a[2 * s], p4 = b0[2 * s], q4 = b1[2 * s];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc0 = mfma(a4[e], p4[e], acc0);
+            acc1 = mfma(a4[e], q4[e], acc1);
+        }
+    }
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float* crow = C + (long)(32 * tm + acc_row(r, hh)) * N + 64 * tn + col;
+        crow[0] = acc0[r];
+        crow[32] = acc1[r];
+    }
+}
+
+// c[i] = sum over the splits' partials in a fixed order: a 64 x 16 block takes 64 float4 elements, thread (x, y) adds the partials
+// y, y + 16, ... with two independent chains, the 16 sums are added in y order through LDS (a serial walk over 1024 partials
+// per element took 100 us)
+__global__ __launch_bounds__(1024) void gemm_reduce_kernel(const f32x4* __restrict__ part, long n4, int splits, f32x4* __restrict__ c) {
+    __shared__ f32x4 sred[16][64];
+    const int x = threadIdx.x, y = threadIdx.y;
+    const long i = (long)blockIdx.x * 64 + x;
+    f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0;
+    if (i < n4) {
+        int q = y;
+        for (; q + 16 < splits; q += 32) {
+            const f32x4 u = part[(long)q * n4 + i], w = part[(long)(q + 16) * n4 + i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s0[e] = s0[e] + u[e];
+                s1[e] = s1[e] + w[e];
+            }
+        }
+        if (q < splits) {
+            const f32x4 u = part[(long)q * n4 + i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s0[e] = s0[e] + u[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s0[e] = s0[e] + s1[e];
+    sred[y][x] = s0;
+    __syncthreads();
+    if (y == 0 && i < n4) {
+        f32x4 s = sred[0][x];
+        for (int q = 1; q < 16; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = s[e] + sred[q][x][e];
+        c[i] = s;
+    }
+}
+
+// how many K ranges launch_gemm_nt_f32 uses: none while the output has at least 1024 blocks (a wave per SIMD); otherwise enough for about
+// two waves per SIMD, at least 8 k-steps of 8 per range, at most 512
+int gemm_nt_splits(int M, int N, int K) {
+    const long tiles = (long)(M / 32) * (N / 64);
+    if (tiles >= 1024) return 1;
+    long want = (2048 + tiles - 1) / tiles;
+    const long most = K / 64 > 0 ? K / 64 : 1;
+    if (want > most) want = most;
+    if (want > 512) want = 512;
+    return want < 1 ? 1 : (int)want;
+}
+
+hipError_t launch_gemm_nt_f32(const float* A, const float* Bt, float* C, int M, int N, int K, float* scratch, hipStream_t st) {
+    const int tiles = (M / 32) * (N / 64), splits = gemm_nt_splits(M, N, K);
+    if (splits > 1 && !scratch) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3((unsigned)((tiles + 3) / 4), (unsigned)splits), dim3(256), 0, st, A, Bt, splits > 1 ? scratch : C,
+                       M, N, K, splits);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || splits == 1) return e;
+    const long n4 = (long)M * N / 4;
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64, 16), 0, st, reinterpret_cast<const f32x4*>(scratch), n4, splits,
+                       reinterpret_cast<f32x4*>(C));
+    return hipGetLastError();
+}
+
+// ---- C[N][K] = sum_m G[m][N] A[m][K]: the weight gradient g^T . x with BOTH operands as they lie (row-major over the M rows that are
+// contracted) - a transposed copy of a 64 512 x 128 activation costs 36-90 us, more than the product.  One wave per 32 (n) x 64 (k) block;
+// a lane's 4 k-slots of 8 consecutive rows m are 4 dword loads per operand block (32 lanes read 128 contiguous bytes of a row).
+__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float* __restrict__ G, const float* __restrict__ A, float* __restrict__ C,
+                                                          int M, int N, int K, int splits) {
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int tiles_k = K / 64;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= (N / 32) * tiles_k) return;
+    const int tn = t / tiles_k, tk = t % tiles_k;
+    const float* g = G + 32 * tn + i;
+    const float* a0 = A + 64 * tk + i;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc0[r] = 0.0f;
+        acc1[r] = 0.0f;
+    }
+    const int steps = M / 8, split = (int)blockIdx.y;
+    const int s_begin = (int)((long)steps * split / splits), s_end = (int)((long)steps * (split + 1) / splits);
+    C += (long)split * N * K;
+#pragma unroll 2
+    for (int s = s_begin; s < s_end; ++s) {
+        const long m0 = 8L * s + 4 * h;
+        float gv[4], p[4], q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gv[e] = g[(m0 + e) * N];
+            p[e] = a0[(m0 + e) * K];
+            q[e] = a0[(m0 + e) * K + 32];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc0 = mfma(gv[e], p[e], acc0);
+            acc1 = mfma(gv[e], q[e], acc1);
+        }
+    }
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float* crow = C + (long)(32 * tn + acc_row(r, hh)) * K + 64 * tk + col;
+        crow[0] = acc0[r];
+        crow[32] = acc1[r];
+    }
+}
+
+int gemm_tn_splits(int M, int N, int K) { return gemm_nt_splits(N, K, M); }
+
+hipError_t launch_gemm_tn_f32(const float* G, const float* A, float* C, int M, int N, int K, float* scratch, hipStream_t st) {
+    const int tiles = (N / 32) * (K / 64), splits = gemm_tn_splits(M, N, K);
+    if (splits > 1 && !scratch) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((unsigned)((tiles + 3) / 4), (unsigned)splits), dim3(256), 0, st, G, A, splits > 1 ? scratch : C,
+                       M, N, K, splits);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || splits == 1) return e;
+    const long n4 = (long)N * K / 4;
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64, 16), 0, st, reinterpret_cast<const f32x4*>(scratch), n4, splits,
+                       reinterpret_cast<f32x4*>(C));
+    return hipGetLastError();
+}
+
+}  // namespace mvnerf

@@ -80,6 +80,10 @@ hipError_t launch_finish_view(const float* rgb, const float* depth, long n, floa
                               hipStream_t st);
 
 // train_ops.hip
+hipError_t launch_gemm_nt_f32(const float* A, const float* Bt, float* C, int M, int N, int K, float* scratch, hipStream_t st);
+int gemm_nt_splits(int M, int N, int K);
+hipError_t launch_gemm_tn_f32(const float* G, const float* A, float* C, int M, int N, int K, float* scratch, hipStream_t st);
+int gemm_tn_splits(int M, int N, int K);
 hipError_t launch_pack_bwd_streams(const float* net_keras, float* dst, hipStream_t st);
 hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, float* d_o,
                            float* d_d, float* d_features, hipStream_t st);

@@ -86,6 +86,76 @@ class TrunkField(torch.autograd.Function):
 
 
 # ---- GraspReadout (delta_ngf/layers.py:8-42) ----------------------------------------------------------------
+def _skinny(m, n, k):
+    """Products mvnerf_gemm_nt takes over from the library GEMM: every shape it accepts.  On the GraspReadout's shapes the library picks
+    poor kernels - 4 to 36 workgroups for the weight gradients (64 x 128 outputs over K = 64 512 rows: 245 us) and for the 2688-input block
+    (1536 x 128 over K = 2688), 16 x 16 tiles for 64 512 x 128 x 64 (590 us) - see profiles/r02_language_step_trace.md."""
+    return ops.gemm_nt_ok(m, n, k) and k >= 64
+
+
+def _mm_nt_raw(a, bt):
+    if a.is_cuda and a.dtype == torch.float32 and bt.dtype == torch.float32 and _skinny(a.shape[0], bt.shape[0], a.shape[1]):
+        return ops.gemm_nt(a.contiguous(), bt.contiguous())
+    return a @ bt.t()
+
+
+def _tn_skinny(m, n, k):
+    return ops.gemm_tn_ok(m, n, k) and m >= 64
+
+
+class _MatmulNT(torch.autograd.Function):
+    """a (M,K) @ bt (N,K)^T with the skinny products on mvnerf_gemm_nt.  The backward is built from this function and _MatmulTN again, so
+    the second derivatives LanguageNeRF.train_step takes (model_v4.py:290-322) choose their kernels the same way (a large forward
+    product has a skinny weight gradient)."""
+
+    @staticmethod
+    def forward(ctx, a, bt):
+        ctx.save_for_backward(a, bt)
+        return _mm_nt_raw(a, bt)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, bt = ctx.saved_tensors
+        ga = _MatmulNT.apply(g, bt.t()) if ctx.needs_input_grad[0] else None               # g (M,N) @ bt (N,K): bt^T is a small copy
+        gbt = _MatmulTN.apply(g, a) if ctx.needs_input_grad[1] else None                   # g^T (N,M) @ a (M,K), operands as they lie
+        return ga, gbt
+
+
+class _MatmulTN(torch.autograd.Function):
+    """g (M,N)^T @ a (M,K) -> (N,K): a weight gradient, without transposed copies of the M-row operands (mvnerf_gemm_tn)."""
+
+    @staticmethod
+    def forward(ctx, g, a):
+        ctx.save_for_backward(g, a)
+        if g.is_cuda and g.dtype == torch.float32 and a.dtype == torch.float32 and _tn_skinny(g.shape[0], g.shape[1], a.shape[1]):
+            return ops.gemm_tn(g.contiguous(), a.contiguous())
+        return g.t() @ a
+
+    @staticmethod
+    def backward(ctx, c):
+        g, a = ctx.saved_tensors
+        gg = _MatmulNT.apply(a, c) if ctx.needs_input_grad[0] else None                    # a (M,K) @ c (N,K)^T -> (M,N)
+        ga = _MatmulNT.apply(g, c.t()) if ctx.needs_input_grad[1] else None                # g (M,N) @ c (N,K) -> (M,K): c^T is a small copy
+        return gg, ga
+
+
+def _mm_nt(a, bt):
+    """a @ bt^T through _MatmulNT on the GPU (fp32), plain torch otherwise."""
+    if a.is_cuda and a.dtype == torch.float32 and bt.dtype == torch.float32:
+        return _MatmulNT.apply(a, bt)
+    return a @ bt.t()
+
+
+def _wide_linear(lin, x):
+    """nn.Linear through _mm_nt (value, input / weight gradients and their derivatives)."""
+    if not x.is_cuda:
+        return lin(x)
+    y = _mm_nt(x.reshape(-1, lin.in_features), lin.weight)
+    if lin.bias is not None:
+        y = y + lin.bias
+    return y.reshape(*x.shape[:-1], lin.out_features)
+
+
 def _he_normal_(w):
     fan_in = w.shape[1]
     nn.init.trunc_normal_(w, std=math.sqrt(2.0 / fan_in) / 0.87962566103423978, a=-2 * math.sqrt(2.0 / fan_in) / 0.87962566103423978,
@@ -106,8 +176,8 @@ class ResNetMLPBlock(nn.Module):
                 nn.init.zeros_(lin.bias)
 
     def forward(self, x):
-        r = self.layer_1(nn.functional.elu(self.layer_0(nn.functional.elu(x))))
-        return (self.shortcut(x) if self.shortcut is not None else x) + r
+        r = _wide_linear(self.layer_1, nn.functional.elu(_wide_linear(self.layer_0, nn.functional.elu(x))))
+        return (_wide_linear(self.shortcut, x) if self.shortcut is not None else x) + r
 
 
 class GraspReadout(nn.Module):
@@ -129,8 +199,8 @@ class GraspReadout(nn.Module):
 
     def forward(self, acts):
         """acts: 4 x (B, np, n5, 128) -> (B, np)."""
-        ds = [nn.functional.elu(lin(a)) for lin, a in zip(self.activation_downscale, acts)]
-        x = nn.functional.elu(self.combined_activation_downscale(torch.cat(ds, -1)))
+        ds = [nn.functional.elu(_wide_linear(lin, a)) for lin, a in zip(self.activation_downscale, acts)]
+        x = nn.functional.elu(_wide_linear(self.combined_activation_downscale, torch.cat(ds, -1)))
         x = x.reshape(x.shape[0], x.shape[1], -1)                                # 'b np n5 d -> b np (n5 d)'
         x = self.block_1(self.block_0(x))
         return self.output_layer(torch.relu(x))[..., 0]
@@ -249,13 +319,22 @@ class LanguageNeRF(nn.Module):
         f32 = lambda t: torch.as_tensor(t, dtype=torch.float32).to(dev)
         return TrunkState(f32(inputs[4]), f32(batched_features), f32(inputs[5]), f32(inputs[6]), self.trunk_net)
 
+    def _query_points(self, transforms):
+        """poses = transforms @ offsets (model_v4.py:222-226) reduced to what is used of them: points = the poses' translations, dirs =
+        their z axes.  With affine offsets (last row 0 0 0 1) that is R t_o + t and R z_o - two (B np 3, 3) x (3, n5) products instead of
+        B np n5 batched 4 x 4 products, for which the library GEMM takes 590 us (16 x 16 tiles over 64 512 batches)."""
+        rot, trans = transforms[..., :3, :3], transforms[..., :3, 3]
+        off_t, off_z = self.transforms_to_check[:, :3, 3], self.transforms_to_check[:, :3, 2]      # (n5, 3)
+        points = torch.einsum('bpik,ok->bpoi', rot, off_t) + trans[:, :, None, :]
+        dirs = torch.einsum('bpik,ok->bpoi', rot, off_z)
+        b = transforms.shape[0]
+        return points.reshape(b, -1, 3), dirs.reshape(b, -1, 3)                                     # query order (np, n5)
+
     def _call(self, inputs, transforms, n_points, batched_features, state=None):
         """model_v4.py:211-265: poses = transforms @ offsets; points = their translations, directions = their z axes;
         trunk -> fused activations (b, np, n5, 128) x 4 -> GraspReadout -> (B, np)."""
         state = state or self.trunk_state(inputs, batched_features)
-        poses = transforms[:, :, None] @ self.transforms_to_check[None, None]          # (B, np, n5, 4, 4)
-        points = poses[..., :3, 3].reshape(transforms.shape[0], -1, 3)                  # query order (np, n5)
-        dirs = poses[..., :3, 2].reshape(transforms.shape[0], -1, 3)                    # R @ [0,0,1]
+        points, dirs = self._query_points(transforms)
         acts = TrunkField.apply(points, dirs, state)                                     # (4, B, np*n5, 128)
         acts = acts.reshape(N_FUSED, transforms.shape[0], n_points, self.n_transforms_to_check, 128)
         return self.grasp_readout(list(acts.unbind(0)))
@@ -269,10 +348,8 @@ class LanguageNeRF(nn.Module):
             if compute_dtype != 'bf16':
                 raise ValueError("compute_dtype must be 'f32' or 'bf16'")
             state = self.trunk_state(inputs, batched_features)
-            poses = transforms[:, :, None] @ self.transforms_to_check[None, None]
             b = transforms.shape[0]
-            points = poses[..., :3, 3].reshape(b, -1, 3).contiguous()
-            dirs = poses[..., :3, 2].reshape(b, -1, 3).contiguous()
+            points, dirs = (t.contiguous() for t in self._query_points(transforms))
             z = torch.zeros(b, points.shape[1], 1, dtype=torch.float32, device=self.device_)
             _, acts = ops.field_eval_bf16(points, dirs, z, *state.geo, state.packed, ops.pack_net_bf16(self.trunk_net),
                                           return_fused_acts=True)

@@ -545,6 +545,46 @@ def field_backward(rays_o, rays_d, z, images, features, intrinsics, extrinsics_i
     return scratch
 
 
+def gemm_nt_ok(m, n, k):
+    """Shapes mvnerf_gemm_nt takes."""
+    return m > 0 and n > 0 and k > 0 and m % 32 == 0 and n % 64 == 0 and k % 8 == 0
+
+
+def gemm_nt(a, bt):
+    """mvnerf_gemm_nt: a (M,K) @ bt (N,K)^T -> (M,N), fp32, deterministic (K split into ranges whose partials are added in order)."""
+    m, k = a.shape
+    n = bt.shape[0]
+    _chk(a, 'a', shape=(m, k))
+    _chk(bt, 'bt', shape=(n, k))
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    need = int(_lib.lib().mvnerf_gemm_nt_scratch_bytes(m, n, k))
+    scratch = torch.empty(need, dtype=torch.uint8, device=a.device) if need else None
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().mvnerf_gemm_nt(_p(a), _p(bt), _p(out), m, n, k, _p(scratch), _stream(a))
+    _lib.check(rc, 'gemm_nt')
+    return out
+
+
+def gemm_tn_ok(m, n, k):
+    """Shapes mvnerf_gemm_tn takes."""
+    return m > 0 and n > 0 and k > 0 and m % 8 == 0 and n % 32 == 0 and k % 64 == 0
+
+
+def gemm_tn(g, a):
+    """mvnerf_gemm_tn: g (M,N)^T @ a (M,K) -> (N,K), fp32, deterministic; no transposed copies."""
+    m, n = g.shape
+    k = a.shape[1]
+    _chk(g, 'g', shape=(m, n))
+    _chk(a, 'a', shape=(m, k))
+    out = torch.empty((n, k), dtype=torch.float32, device=a.device)
+    need = int(_lib.lib().mvnerf_gemm_tn_scratch_bytes(m, n, k))
+    scratch = torch.empty(need, dtype=torch.uint8, device=a.device) if need else None
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().mvnerf_gemm_tn(_p(g), _p(a), _p(out), m, n, k, _p(scratch), _stream(a))
+    _lib.check(rc, 'gemm_tn')
+    return out
+
+
 def set_deterministic(on=True):
     """mvnerf_set_deterministic.  Weight gradients are ALWAYS summed in a fixed order since round 2 (stored per-workgroup partials +
     a parallel fixed-order reduction turned out faster than fp32 atomics); the call is kept for its callers, records the flag and
