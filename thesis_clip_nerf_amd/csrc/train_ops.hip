@@ -979,142 +979,16 @@ hipError_t launch_view_broadcast(const float* g_fused, int V, long tiles_per_b, 
 }
 
 // ---- layer-0 weight gradient: dW0[k][n] += sum_rows X0[k] g0[n], db0 += sum g0 (all view rows) ---------------
-// X0 = [PE(cam xyz) 60 | PE(cam dir) 60 | 2 rgb - 1 (3) | features 256] is recomputed per tile in "lane =
-// input row" form (a lane owns one Keras row k and evaluates it for the 16 samples of its half), which is the
-// MFMA A-operand layout; the feature rows are coalesced 128-B gathers of 32 consecutive channels per tap.
-struct SampleGeom {       // per sample, in wave-private LDS
+// X0 = [PE(cam xyz) 60 | PE(cam dir) 60 | 2 rgb - 1 (3) | features 256] is recomputed per tile (dw0_split8_kernel below).
+struct SampleGeom {       // per sample, in LDS
     float cam[3], dir[3], ax, ay;
     int tl;
 };
 
-// The 120 positional-encoding rows are evaluated per tile in "lane = sample" form - 6 accurate sin/cos and the
-// forward kernel's double-angle recurrence per sample instead of one libm-grade sin/cos per (row, sample) - into a
-// wave-private LDS table [sample][121] and read back transposed as A operands (blockIdx.y == 0 only).
-constexpr int kPeRow = 121;           // odd row stride: conflict-free "lane = sample" writes
-
-__global__ __launch_bounds__(256) void dw0_kernel(FieldParams p, const float* __restrict__ g0_tl, float* __restrict__ dW0,
-                                                  float* __restrict__ db0, int y0, long part_stride) {
-    __shared__ SampleGeom geom[4][32];
-    extern __shared__ float pe_lds[];                      // 4 x 32 x kPeRow floats for the launch with the PE row blocks
-    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* pe_tab = pe_lds + w * (32 * kPeRow);
-    const int kb = (blockIdx.y + y0) * 4 + w;              // 12 row blocks of 32 (384 >= 379)
-    const int krow = 32 * kb + i;
-    f32x16 acc[4];
-    float dbacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
-    SampleGeom* gm = geom[w];
-    const long view_tiles = p.n_tiles * p.V;
-    for (long tile = blockIdx.x; tile < view_tiles; tile += gridDim.x) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (h == 0) {                                      // geometry of sample j = i of this view tile
-            const ViewRow vr = view_row(p, tile * 32 + i);
-            const int ray = vr.ray, b = vr.bv;             // `b` indexes the (B*V) cameras / grids below
-            const float* E = p.einv + 16 * b;
-            const float zz = p.z[vr.g];
-            const float dx = p.rays_d[3 * ray], dy = p.rays_d[3 * ray + 1], dz = p.rays_d[3 * ray + 2];
-            const float wx = p.rays_o[3 * ray] + zz * dx, wy = p.rays_o[3 * ray + 1] + zz * dy, wz = p.rays_o[3 * ray + 2] + zz * dz;
-            float cam[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cam[r] = row_dot4(E, r, wx, wy, wz, 1.0f);
-            float px, py;
-            pixel_from_cam(p.k4 + 16 * b, cam, &px, &py);
-            const Taps tp = bilinear_taps(px, py, p.H, p.W);
-            SampleGeom sg;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                sg.cam[r] = cam[r];
-                sg.dir[r] = row_dot4(E, r, dx, dy, dz, 1.0f);
-            }
-            sg.ax = tp.ax;
-            sg.ay = tp.ay;
-            sg.tl = (b * p.H + tp.y0) * p.W + tp.x0;
-            gm[i] = sg;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (kb < 4) {                                      // wave-uniform: this wave's rows include PE rows
-            // lane (sample i, half h): h = 0 the camera point, h = 1 the camera direction; rows 60h + 20d + 2k + {sin, cos}
-            const SampleGeom sgm = gm[i];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float a0 = (h ? sgm.dir[d] : sgm.cam[d]) * 3.14159274101257324f;
-                float sk = 0.0f, ck = 0.0f;
-#pragma unroll
-                for (int k = 0; k < kNFreq; ++k) {
-                    if (k == 0 || k == 5) {
-                        sincos_f32(a0 * (float)(1 << k), &sk, &ck);
-                    } else {                               // octave k is the double angle of octave k - 1 (field_eval.hip)
-                        const float s2 = sk + sk;
-                        const float cn = fmaf(-s2, sk, 1.0f);
-                        sk = s2 * ck;
-                        ck = cn;
-                    }
-                    pe_tab[i * kPeRow + 60 * h + 20 * d + 2 * k] = sk;
-                    pe_tab[i * kPeRow + 60 * h + 20 * d + 2 * k + 1] = ck;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        f32x4 a4[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const SampleGeom sg = gm[8 * t + 4 * h + e];
-                float v = 0.0f;
-                if (krow < 120) {                          // positional encodings, layout (d, k, {sin,cos})
-                    v = pe_tab[(8 * t + 4 * h + e) * kPeRow + krow];
-                } else if (krow < 123) {
-                    const float* im = p.images + 3 * (long)sg.tl + (krow - 120);
-                    v = bilerp(im[0] * 2.0f - 1.0f, im[3] * 2.0f - 1.0f, im[3 * p.W] * 2.0f - 1.0f,
-                               im[3 * p.W + 3] * 2.0f - 1.0f, sg.ax, sg.ay);
-                } else if (krow < 379) {
-                    const float* f = p.features + 256 * (long)sg.tl + (krow - 123);
-                    v = bilerp(f[0], f[256], f[256 * (long)p.W], f[256 * (long)p.W + 256], sg.ax, sg.ay);
-                }
-                a4[t][e] = v;
-            }
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const f32x4* gp = reinterpret_cast<const f32x4*>(g0_tl + tl_index(tile, 128, 32 * nb + i, 4 * h));
-            float s = 0.0f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f32x4 g4 = gp[2 * t];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[nb] = mfma(a4[t][e], g4[e], acc[nb]);
-                    s = s + g4[e];
-                }
-            }
-            dbacc[nb] = dbacc[nb] + s;
-        }
-    }
-    const int col = lane & 31, hh = lane >> 5;
-    const bool store = part_stride != 0;
-    dW0 += (long)blockIdx.x * part_stride;
-    db0 += (long)blockIdx.x * part_stride;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = 32 * kb + acc_row(r, hh);
-            if (k < kIn) grad_out(dW0 + (long)k * kHidden + 32 * nb + col, acc[nb][r], store);
-        }
-        if (kb == 0) {
-            const float s = dbacc[nb] + __shfl_xor(dbacc[nb], 32);
-            if (hh == 0) grad_out(db0 + 32 * nb + col, s, store);
-        }
-    }
-}
-
-// ---- the same gradient with the GEMM on the bf16 matrix pipe (exactly cut operands), one 8-wave workgroup per CU -----------------
-// dw0_kernel above spends 768 fp32 MFMAs per tile (49 k matrix cycles), recomputes the geometry in each of its 12 waves and, like
-// every wave issuing v_mfma_f32_32x32x2_f32, cannot hide its gathers / lerps behind its own MFMAs.  Here, per tile of 32 samples:
+// ---- the GEMM on the bf16 matrix pipe (exactly cut operands), one 8-wave workgroup per CU ------------------------------------------
+// The round-1 form (two launches of 4-wave workgroups, one wave per 32-row block, fp32 MFMA) spent 768 fp32 MFMAs per tile (49 k matrix
+// cycles), recomputed the geometry in each of its 12 waves and, like every wave issuing v_mfma_f32_32x32x2_f32, could not hide its
+// gathers / lerps behind its own MFMAs (1 343 us at 16 384 tiles).  Here, per tile of 32 samples:
 //   * X0 (384 rows x 32 samples) is built ONCE by the 512 threads, cut into three bf16 pieces and laid out in LDS in A-operand order
 //     (XA, 72 KiB); G is cut once into B-operand order (PB, 24 KiB) - as in dense_bwd_split8_kernel;
 //   * wave v owns output block nb = v % 4 of six row blocks (6 (v / 4) ..): 72 bf16 MFMAs per tile, 96 accumulator registers;
@@ -1140,7 +1014,6 @@ __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
     const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
     u32x4_t* sP = reinterpret_cast<u32x4_t*>(sbuf);
-    const float* sF = reinterpret_cast<const float*>(sbuf);
     float* pe_tab = reinterpret_cast<float*>(sbuf + kDw8Pe);
     SampleGeom* geom = reinterpret_cast<SampleGeom*>(sbuf + kDw8Geom);          // [2][32]
     GeomQ* geomq = reinterpret_cast<GeomQ*>(sbuf + kDw8GeomQ);                  // [2][32]
@@ -1380,9 +1253,6 @@ __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const
         }
 }
 
-#ifndef MVT_DW0_SPLIT8
-#define MVT_DW0_SPLIT8 1   // 1: dw0_split8_kernel; 0: dw0_kernel (fp32 MFMA, two launches)
-#endif
 hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, float* db0, int max_wgs, float* part, hipStream_t st) {
     const long view_tiles = p.n_tiles * p.V;
     if (view_tiles <= 0 || view_tiles > 0x7fffffffL) return hipErrorInvalidValue;
@@ -1390,32 +1260,18 @@ hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, floa
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    const int pe_bytes = 4 * 32 * kPeRow * (int)sizeof(float);
     if (dev >= 0 && dev < 16 && !attr_done[dev].load(std::memory_order_acquire)) {
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pe_bytes)) != hipSuccess)
-            return e;
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw0_split8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDw8LdsBytes)) != hipSuccess)
             return e;
         attr_done[dev].store(true, std::memory_order_release);
     }
-    if (part && db0 != dW0 + kIn * kHidden) return hipErrorInvalidValue;       // one span [dW0 | db0]
+    if (!part || db0 != dW0 + kIn * kHidden) return hipErrorInvalidValue;      // one span [dW0 | db0], reduced from per-workgroup partials
     const int span = kIn * kHidden + kHidden;
-    float* dWk = part ? part : dW0;
-    float* dbk = part ? part + kIn * kHidden : db0;
-    const long stride = part ? span : 0;
-#if MVT_DW0_SPLIT8
     const unsigned wgs = (unsigned)(view_tiles < max_wgs / 2 ? view_tiles : max_wgs / 2);      // one 512-thread workgroup per CU
-    hipLaunchKernelGGL(dw0_split8_kernel, dim3(wgs), dim3(512), kDw8LdsBytes, st, p, g0_tl, dWk, dbk, stride);
-#else
-    // two launches: row blocks 0..3 (PE rows; 62 KiB of PE tables per workgroup) and row blocks 4..11 (feature rows, no
-    // dynamic LDS, full occupancy)
-    const unsigned wgs = (unsigned)(view_tiles < max_wgs ? view_tiles : max_wgs);
-    hipLaunchKernelGGL(dw0_kernel, dim3(wgs, 1), dim3(256), pe_bytes, st, p, g0_tl, dWk, dbk, 0, stride);
-    hipLaunchKernelGGL(dw0_kernel, dim3(wgs, 2), dim3(256), 0, st, p, g0_tl, dWk, dbk, 1, stride);
-#endif
+    hipLaunchKernelGGL(dw0_split8_kernel, dim3(wgs), dim3(512), kDw8LdsBytes, st, p, g0_tl, part, part + kIn * kHidden, (long)span);
     e = hipGetLastError();
-    if (e != hipSuccess || !part) return e;
-    return launch_reduce_partials(part, stride, (int)wgs, span, dW0, st);
+    if (e != hipSuccess) return e;
+    return launch_reduce_partials(part, span, (int)wgs, span, dW0, st);
 }
 
 // ---- gradient of the field w.r.t. the sample depths (single view) ----------------------------------------------
