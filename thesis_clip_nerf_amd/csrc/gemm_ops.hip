@@ -36,14 +36,24 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     const int steps = K / 8, split = (int)blockIdx.y;
     const int s_begin = (int)((long)steps * split / splits), s_end = (int)((long)steps * (split + 1) / splits);
     C += (long)split * M * N;                                // (splits > 1: C is the partial buffer)
-#pragma unroll 4
+    // the operands of step s + 1 are requested before the MFMAs of step s
+    f32x4 a4 = {0.0f, 0.0f, 0.0f, 0.0f}, p4 = a4, q4 = a4;
+    if (s_begin < s_end) {
+        a4 = a[2 * s_begin];
+        p4 = b0[2 * s_begin];
+        q4 = b1[2 * s_begin];
+    }
     for (int s = s_begin; s < s_end; ++s) {
-        const f32x4 a4 = a[2 * s], p4 = b0[2 * s], q4 = b1[2 * s];
+        const int sn = s + 1 < s_end ? s + 1 : s;
+        const f32x4 an = a[2 * sn], pn = b0[2 * sn], qn = b1[2 * sn];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             acc0 = mfma(a4[e], p4[e], acc0);
             acc1 = mfma(a4[e], q4[e], acc1);
         }
+        a4 = an;
+        p4 = pn;
+        q4 = qn;
     }
     const int col = lane & 31, hh = lane >> 5;
 #pragma unroll
@@ -137,20 +147,36 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float* __restric
     const int steps = M / 8, split = (int)blockIdx.y;
     const int s_begin = (int)((long)steps * split / splits), s_end = (int)((long)steps * (split + 1) / splits);
     C += (long)split * N * K;
-#pragma unroll 2
-    for (int s = s_begin; s < s_end; ++s) {
-        const long m0 = 8L * s + 4 * h;
-        float gv[4], p[4], q[4];
+    // the operands of step s + 1 are requested before the MFMAs of step s
+    float gv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, p[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (s_begin < s_end) {
+        const long m0 = 8L * s_begin + 4 * h;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             gv[e] = g[(m0 + e) * N];
             p[e] = a0[(m0 + e) * K];
             q[e] = a0[(m0 + e) * K + 32];
         }
+    }
+    for (int s = s_begin; s < s_end; ++s) {
+        const long m1 = 8L * (s + 1 < s_end ? s + 1 : s) + 4 * h;
+        float gn[4], pn[4], qn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gn[e] = g[(m1 + e) * N];
+            pn[e] = a0[(m1 + e) * K];
+            qn[e] = a0[(m1 + e) * K + 32];
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             acc0 = mfma(gv[e], p[e], acc0);
             acc1 = mfma(gv[e], q[e], acc1);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gv[e] = gn[e];
+            p[e] = pn[e];
+            q[e] = qn[e];
         }
     }
     const int col = lane & 31, hh = lane >> 5;
