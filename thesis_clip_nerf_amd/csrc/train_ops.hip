@@ -630,13 +630,17 @@ hipError_t launch_dense_bwd_fused(const float* g_tl, const float* a_tl, const fl
                                   float* da_tl, long n_tiles, float* dW, float* db, int max_wgs, float* part, hipStream_t st) {
     // `part` != nullptr (deterministic mode): every workgroup stores its partial of the span [dW | db] (db directly behind dW) and
     // launch_reduce_partials adds them in a fixed order; otherwise fp32 atomics straight onto the gradient.
-    static std::atomic<bool> attr_done{false};
-    if (!attr_done.load(std::memory_order_acquire)) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsBytes);
+    static std::atomic<bool> attr_done[16];               // first call per device sets the dynamic-LDS limits (idempotent)
+    int dev = 0;
+    hipError_t ea = hipGetDevice(&dev);
+    if (ea != hipSuccess) return ea;
+    if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    if (!attr_done[dev].load(std::memory_order_acquire)) {
+        ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsBytes);
         if (ea == hipSuccess)
             ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_bwd_split8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBwd8LdsBytes);
         if (ea != hipSuccess) return ea;
-        attr_done.store(true, std::memory_order_release);
+        attr_done[dev].store(true, std::memory_order_release);
     }
     if (n_tiles <= 0 || n_tiles > 0x7fffffffL) return hipErrorInvalidValue;                // tile indices are 32-bit inside the kernels
     if (!dW) {                                             // frozen trunk (query_vjp): two 256-thread workgroups per CU
