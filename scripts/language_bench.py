@@ -27,6 +27,7 @@ ap.add_argument('--points', type=int, default=192, help='poses per scene (x 42 o
 ap.add_argument('--size', type=int, nargs=2, default=[480, 640])
 ap.add_argument('--views', type=int, default=1)
 ap.add_argument('--steps', type=int, default=10)
+ap.add_argument('--only-train', action='store_true', help='time the train step only (for kernel traces)')
 args = ap.parse_args()
 dev = 'cuda:0'
 h, w = args.size
@@ -78,7 +79,7 @@ def timed(fn, steps=args.steps):
 
 z0 = torch.zeros(b, points.shape[1], 1, device=dev)
 packed16 = ops.pack_net_bf16(model.trunk_net)
-res = {
+res = {'train_step': timed(lambda: model.train_step((inputs, labels), feats), max(2, args.steps // 2))} if args.only_train else {
     'forward bf16': timed(lambda: ops.field_eval_bf16(points, dirs, z0, *geo, state.packed, packed16, return_fused_acts=True)),
     'forward': timed(lambda: ops.query_field(points, dirs, *geo, state.packed, complete_output=True)),
     'forward+stash': timed(lambda: ops.query_stash(points, dirs, *geo, state.packed, stash)),
