@@ -220,8 +220,9 @@ int mvnerf_finish_view(const float* rgb, const float* depth, long n, float* minm
  * Gradients of every MLP variable, including the path through the importance samples that the reference leaves
  * open (no stop_gradient).  V > 1 needs R*S to be a multiple of 32. */
 
-/* Bytes of the activation stash one mvnerf_field_eval_stash call writes (7 per-view + 7 fused pre-activation
- * tensors in tile layout). */
+/* Bytes of the activation stash of one mvnerf_field_eval_stash call: 7 per-view + 7 fused pre-activation tensors in tile layout
+ * (per view x0 h1 x1 h2 x2 h3 x3, then mean h4 x4 h5 x5 h6 x6).  The per-view slot of x3 is part of the layout but is not written:
+ * nothing reads it (the backward of the view mean needs no activation; for V = 1 it is the fused slot of the mean). */
 size_t mvnerf_stash_bytes(int B, int V, int R, int S);
 /* Weight-gradient reduction of mvnerf_field_backward: every workgroup stores its partial of a layer's [dW | db] span and the partials
  * are summed in workgroup order - bit-identical gradients for identical inputs.  Until the middle of round 2 this was a mode (0 =

@@ -102,7 +102,10 @@ def test_stash_of_split_forward_matches_fp32_stash(views, table):
     rgbs, stash = ops.field_eval_stash(*args, texel_table=tab, packed_split=split)
     torch.cuda.synchronize()
     n = ops.stash_bytes(1, views, 24, 64) // 4
-    a, b = stash.view(torch.float32)[:n], stash32.view(torch.float32)[:n]
+    slot = views * (24 * 64 // 32) * 4096                                      # floats per per-view slot
+    keep = torch.ones(n, dtype=torch.bool, device=DEV)
+    keep[6 * slot:7 * slot] = False                                              # per-view slot 6 (x3) is not written by either kernel
+    a, b = stash.view(torch.float32)[:n][keep], stash32.view(torch.float32)[:n][keep]
     assert (rgbs - rgbs32).abs().max().item() < 1e-5
     assert (a - b).abs().max().item() < 2e-5 * max(1.0, b.abs().max().item())
 

@@ -36,7 +36,8 @@ def test_stash_matches_complete_output():
         per_view = st[:7 * views * tiles * 4096].view(7, views * tiles, 128, 32)
         fused = st[7 * views * tiles * 4096:][:7 * tiles * 4096].view(7, tiles, 128, 32)
         for k in range(4):                       # slots 0,2,4,6 = x0..x3 per view / view mean, x4..x6 fused
-            assert torch.equal(per_view[2 * k].permute(0, 2, 1).reshape(views * n, 128), acts[k].reshape(views * n, 128)), ('view', k)
+            if k < 3:                            # (the per-view slot of x3 is in the layout but is not written: nothing reads it)
+                assert torch.equal(per_view[2 * k].permute(0, 2, 1).reshape(views * n, 128), acts[k].reshape(views * n, 128)), ('view', k)
             assert torch.equal(fused[2 * k].permute(0, 2, 1).reshape(n, 128), acts[4 + k].reshape(n, 128)), ('fused', k)
 
 

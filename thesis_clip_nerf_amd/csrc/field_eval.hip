@@ -86,13 +86,13 @@ __device__ __forceinline__ void dense128(WStream& ws, const f32x16 (&in)[4], f32
 template <bool kStash>
 __device__ __forceinline__ void resnet_block(WStream& ws, const float* __restrict__ bias1, int h, f32x16 (&x)[4],
                                              f32x16 (&hid)[4], float* __restrict__ stash, long slot_stride, long tile,
-                                             int j) {
+                                             int j, bool store_out = true) {
     bias_to_acc<false>(bias1, h, hid);
     dense128(ws, x, hid);
     if (kStash) store_tl(stash, tile, j, h, hid);
     bias_to_acc<true>(bias1 + 128, h, x);
     dense128(ws, hid, x);
-    if (kStash) store_tl(stash + slot_stride, tile, j, h, x);
+    if (kStash && store_out) store_tl(stash + slot_stride, tile, j, h, x);
 }
 
 // kProj: the 256 feature rows of layer 0 come from the texel table (project_texels_kernel) instead of 128 k-steps:
@@ -281,7 +281,8 @@ __global__ __launch_bounds__(kMultiView ? 256 : 64 * MV_WAVES, kMultiView ? MV_M
 #pragma unroll 1
         for (int bi = 0; bi < 3; ++bi) {
             resnet_block<kStash>(ws, net + kPackBHidden + 256 * bi, h, x, hid,
-                                 kStash ? p.stash + (1 + 2 * bi) * p.stash_stride : nullptr, p.stash_stride, vtile, j);
+                                 kStash ? p.stash + (1 + 2 * bi) * p.stash_stride : nullptr, p.stash_stride, vtile, j,
+                                 bi < 2);                               // per-view slot 6 = x3 is not written: nothing reads it
             if (p.acts_view && valid) store_acc(p.acts_view + (bi + 1) * vslot + 128 * vrow, h, x);
         }
 

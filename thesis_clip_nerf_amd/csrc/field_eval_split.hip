@@ -645,7 +645,9 @@ __global__ __launch_bounds__((kMultiView && MVS_MV_W4) ? 256 : 512, (kMultiView 
                 if (kStash && tile_ok) store_tl(p.stash + (1 + 2 * bi) * p.stash_stride, vtile, j, h, hid);
                 bias_acc<true>(bias1 + 128, h, x);
                 dense128_split<kW>(ring, lane, hid, x);
-                if (kStash && tile_ok) store_tl(p.stash + (2 + 2 * bi) * p.stash_stride, vtile, j, h, x);
+                // (per-view slot 6 = x3 is not written: nothing reads it - the backward of the view mean needs no activation, and for
+                //  V = 1 it is fused slot 0)
+                if (kStash && tile_ok && bi < 2) store_tl(p.stash + (2 + 2 * bi) * p.stash_stride, vtile, j, h, x);
                 if (p.acts_view && valid) store_row(p.acts_view + (bi + 1) * vslot + 128 * vrow);
             }
             if (kMultiView) {
