@@ -7,6 +7,7 @@ B scenes x (n_points x 42 offsets) query points, V source views of HxW, fp32.  R
   vjp              mvnerf_query_vjp (12 dX launches + layer-0 input gradient)
   jvp              mvnerf_query_jvp (fused primal + tangent pass)
   train_step       LanguageNeRF.train_step: 2 forwards, VJP, JVP, GraspReadout fwd/bwd/double-bwd in torch, Adam
+  train_step (HIP graph)  the same step after compile(graph=True): one graph replay
 Usage: python scripts/language_bench.py [--batch 8] [--points 192] [--size 480 640] [--views 1] [--steps 10]"""
 import argparse
 import os
@@ -28,6 +29,7 @@ ap.add_argument('--size', type=int, nargs=2, default=[480, 640])
 ap.add_argument('--views', type=int, default=1)
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--only-train', action='store_true', help='time the train step only (for kernel traces)')
+ap.add_argument('--train-mode', choices=['both', 'eager', 'graph'], default='both', help='which train_step legs to run')
 args = ap.parse_args()
 dev = 'cuda:0'
 h, w = args.size
@@ -79,7 +81,7 @@ def timed(fn, steps=args.steps):
 
 z0 = torch.zeros(b, points.shape[1], 1, device=dev)
 packed16 = ops.pack_net_bf16(model.trunk_net)
-res = {'train_step': timed(lambda: model.train_step((inputs, labels), feats), max(2, args.steps // 2))} if args.only_train else {
+res = ({'train_step': timed(lambda: model.train_step((inputs, labels), feats), max(2, args.steps // 2))} if args.train_mode != 'graph' else {}) if args.only_train else {
     'forward bf16': timed(lambda: ops.field_eval_bf16(points, dirs, z0, *geo, state.packed, packed16, return_fused_acts=True)),
     'forward': timed(lambda: ops.query_field(points, dirs, *geo, state.packed, complete_output=True)),
     'forward+stash': timed(lambda: ops.query_stash(points, dirs, *geo, state.packed, stash)),
@@ -87,6 +89,16 @@ res = {'train_step': timed(lambda: model.train_step((inputs, labels), feats), ma
     'jvp': timed(lambda: ops.query_jvp(points, dirs, tp, td, *geo, state.packed)),
     'train_step': timed(lambda: model.train_step((inputs, labels), feats), max(2, args.steps // 2)),
 }
+# the same step captured as one HIP graph (compile(graph=True)): device-resident inputs bound as the graph's buffers
+if args.train_mode != 'eager':
+    gmodel = LanguageNeRF(sc['fine'], n_points_train=npts, n_views=args.views, batch_size=b, rotation_representation='6d',
+                          softmax_before_loss=True, device=dev)
+    gmodel.compile(graph=True)
+    dv = lambda a: torch.from_numpy(a).to(dev)
+    g_inputs = (dv(t1), dv(r1), dv(t2), dv(r2), images, k4, einv)
+    g_labels = tuple(dv(l) for l in labels)
+    gmodel.bind_graph_inputs((g_inputs, g_labels), feats)
+    res['train_step (HIP graph)'] = timed(lambda: gmodel.train_step((g_inputs, g_labels), feats), max(4, args.steps))
 print(f'cfg3 shape: B={b} scenes x {points.shape[1]} query points ({npts} poses x 42 offsets), V={args.views}, {h}x{w}x256 fp32 features '
       f'({feats.numel() * 4 / 1e9:.2f} GB), {n_q} points per pass')
 for k, dt in res.items():

@@ -196,3 +196,41 @@ def test_language_train_step_updates_readout_only():
     assert scores16.shape == (1, 2)
     assert (scores16 - scores).abs().max().item() < 5e-2 * max(1.0, scores.abs().max().item())     # bf16 trunk, fp32 read-out
 
+
+
+def test_language_train_step_graph_replay_matches_eager():
+    """compile(graph=True): two eager steps, then one capture, then replays - against a twin model stepping eagerly on the same data.
+    The inputs change from step to step (staged into the graph's buffers), so a replay that ignored them would show.
+    Phase A, learning rate 0: the weights stand still, every step's losses must agree to fp32 rounding.  Phase B, learning rate 1e-3: Adam's
+    normalised update turns last-bit differences of small gradient entries into lr-sized weight differences, so two models drift apart
+    however they are stepped; the bar there is the distance between the two against the distance both moved."""
+    n_points, steps = 3, 5
+    sc, inputs, labels, eager = _language_case(70, 2, 2, n_points, '6d')
+    rng = np.random.default_rng(7)
+    datas = [((*[(a + 0.05 * rng.standard_normal(a.shape)).astype(np.float32) for a in inputs[:4]], *inputs[4:]), labels) for _ in range(steps)]
+    for lr in (0.0, 1e-3):
+        eager, graphed, start = (_language_case(70, 2, 2, n_points, '6d')[3] for _ in range(3))
+        eager.compile(learning_rate=lr)
+        with pytest.raises(ValueError):
+            graphed.compile(optimizer=torch.optim.SGD(graphed.grasp_readout.parameters(), lr=lr), graph=True)
+        graphed.compile(learning_rate=lr, graph=True)
+        seen = []
+        for step, data in enumerate(datas):
+            out_e = eager.train_step(data, sc['features'])
+            out_g = graphed.train_step(data, sc['features'])
+            bar = 1e-5 if lr == 0.0 else 5e-3
+            for k in out_e:
+                assert abs(float(out_e[k]) - float(out_g[k])) < bar * max(1.0, abs(float(out_e[k]))), (lr, step, k, float(out_e[k]), float(out_g[k]))
+            seen.append(float(out_g['grad_loss_t']))
+        assert graphed._graph is not None
+        if lr == 0.0:
+            assert min(abs(a - b) for a, b in zip(seen[2:], seen[3:])) > 2e-3, seen       # replays follow the staged inputs
+        else:
+            pe, pg, p0 = (list(m.grasp_readout.parameters()) for m in (eager, graphed, start))
+            apart = sum((a - b).abs().sum().item() for a, b in zip(pe, pg))
+            moved = sum((a - c).abs().sum().item() for a, c in zip(pe, p0))
+            assert moved > 0 and apart < 0.1 * moved, (apart, moved)
+    with pytest.raises(ValueError):                          # the capture fixed the shapes
+        graphed.train_step(((*[a[:, :2] for a in inputs[:4]], *inputs[4:]), labels), sc['features'])
+    with pytest.raises(RuntimeError):
+        graphed.bind_graph_inputs(datas[0], sc['features'])

@@ -536,7 +536,7 @@ int mvnerf_field_backward_table(const float* rays_o, const float* rays_d, const 
     const bool via_table = d_features && texel_table && texel_grad;
     if (via_table) {
         const long n_texels = (long)B * V * H * W;
-        MV_TRY(hipMemsetAsync(texel_grad, 0, (size_t)n_texels * 128 * sizeof(float), st));
+        MV_TRY(mvnerf::launch_zero(texel_grad, (size_t)n_texels * 128 * sizeof(float), st));
         MV_TRY(launch_texel_scatter(p, buf[g], texel_grad, st));
         MV_TRY(launch_texel_grad_to_features(texel_grad, net_keras + kKerasW0 + 123 * kHidden, n_texels, d_features, st));
     }
@@ -640,8 +640,8 @@ int mvnerf_query_vjp(const float* points, const float* dirs, const float* images
     auto fused_slot = [&](int m) { return stash + 7 * vslot + (size_t)m * fslot; };
     hipError_t e;
 #define MV_TRY(call) if ((e = (call)) != hipSuccess) return hip_status(e, "mvnerf_query_vjp")
-    MV_TRY(hipMemsetAsync(d_points, 0, (size_t)total * 3 * sizeof(float), st));
-    MV_TRY(hipMemsetAsync(d_dirs, 0, (size_t)total * 3 * sizeof(float), st));
+    MV_TRY(launch_zero(d_points, (size_t)total * 3 * sizeof(float), st));
+    MV_TRY(launch_zero(d_dirs, (size_t)total * 3 * sizeof(float), st));
     // buf[g] holds dL/d(block output); the cotangents of u3, u2, u1 and the view mean enter where those tensors are produced
     MV_TRY(launch_rows_to_tl(g_acts + (size_t)3 * total * 128, total, n_tiles, 0, buf[0], st));
     int g = 0;

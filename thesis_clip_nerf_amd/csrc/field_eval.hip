@@ -554,7 +554,7 @@ hipError_t launch_field_eval(const FieldParams& p_in, hipStream_t stream) {
     p.tile_counter = nullptr;
 #if MV_PERSIST
     p.tile_counter = di.counters + (g_launch_seq.fetch_add(1) % kCounterSlots);
-    if ((e = hipMemsetAsync(p.tile_counter, 0, sizeof(unsigned int), stream)) != hipSuccess) return e;
+    if ((e = launch_zero(p.tile_counter, sizeof(unsigned int), stream)) != hipSuccess) return e;
 #endif
     if ((e = launch_dir_bias(p, stream)) != hipSuccess) return e;
     const int waves = p.V > 1 ? 4 : MV_WAVES;

@@ -89,6 +89,9 @@ hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float
                            float* d_d, float* d_features, hipStream_t st);
 hipError_t launch_texel_scatter(const FieldParams& p, const float* g0_tl, float* texel_grad, hipStream_t st);
 hipError_t launch_texel_grad_to_features(const float* texel_grad, const float* w0_feat, long n_texels, float* d_features, hipStream_t st);
+// Zero `bytes` (a multiple of 4, dword-aligned) with a kernel.  Used instead of hipMemsetAsync: a memset node captured into a HIP graph from
+// the autograd thread did not run on the graph's later launches (ROCm 7.2; LanguageNeRF.compile(graph=True) replays these paths).
+hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t st);
 hipError_t launch_rows_to_tl(const float* rows, long n_rows, long n_tiles, int accumulate, float* out_tl, hipStream_t st);
 hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int g_feats, long n_tiles, float* dW, int ldn,
                           int n_valid, float* db, int max_wgs, float* part, hipStream_t st);

@@ -928,9 +928,23 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(const float* __restric
     }
 }
 
+__global__ void zero_kernel(unsigned* __restrict__ p, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0u;
+}
+
+hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    if (bytes % 4 != 0 || reinterpret_cast<uintptr_t>(ptr) % 4 != 0) return hipErrorInvalidValue;
+    const size_t n = bytes / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, st, static_cast<unsigned*>(ptr), n);
+    return hipGetLastError();
+}
+
 hipError_t launch_readout_bwd(const float* x_tl, const float* rgbs, const float* d_rgbs, const float* wr, long n_rows,
                               long n_tiles, float* do_tl, float* g_tl, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(do_tl, 0, (size_t)n_tiles * 32 * 32 * sizeof(float), st);
+    hipError_t e = launch_zero(do_tl, (size_t)n_tiles * 32 * 32 * sizeof(float), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(readout_bwd_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, x_tl, rgbs, d_rgbs, wr,
                        n_rows, n_tiles, do_tl, g_tl);

@@ -298,10 +298,18 @@ class LanguageNeRF(nn.Module):
         self.to(self.device_)
 
     # -- reference API --
-    def compile(self, optimizer=None, loss=None, learning_rate=1e-4):
-        self.optimizer = optimizer or torch.optim.Adam(self.grasp_readout.parameters(), lr=learning_rate, eps=1e-7)
+    def compile(self, optimizer=None, loss=None, learning_rate=1e-4, graph=False):
+        """graph=True: `train_step` is captured ONCE as a HIP graph (torch.cuda.CUDAGraph) and replayed: the step is ~400 launches of
+        3-500 us, a third of its wall time is launch latency (profiles/r02_language_step_trace.md).  The graph fixes shapes and addresses:
+        inputs are staged into the buffers `graph_inputs()` returns (a producer that writes `combined_features` there in place skips the
+        copy), the optimizer is this method's own Adam (capturable).  The first two steps run eagerly (they load every kernel and size
+        the allocator pools), the third is captured."""
+        if graph and optimizer is not None:
+            raise ValueError('graph=True builds its own capturable Adam; pass learning_rate instead of an optimizer')
+        self.optimizer = optimizer or torch.optim.Adam(self.grasp_readout.parameters(), lr=learning_rate, eps=1e-7, capturable=bool(graph))
         if loss is not None:
             self.loss = loss
+        self._graph_mode, self._graph, self._g_static, self._g_out, self._g_calls = bool(graph), None, None, None, 0
 
     def set_pose(self, translations, rotations):
         with torch.no_grad():
@@ -382,12 +390,74 @@ class LanguageNeRF(nn.Module):
         return {'landscape_loss': landscape_loss.detach().mean(), 'grad_loss_t': loss_t.detach(), 'grad_loss_r': loss_r.detach(),
                 'pred': prediction.detach().mean()}, prediction.detach()
 
-    def train_step(self, data, combined_features):
-        if self.optimizer is None:
-            self.compile()
-        out, _ = self.loss_and_grads(data, combined_features)
+    def _clip_and_step(self):
         for prm in self.grasp_readout.parameters():                      # optimize(): clip-by-value 1.0, then Adam
             if prm.grad is not None:
                 prm.grad.clamp_(-1.0, 1.0)
         self.optimizer.step()
+
+    def train_step(self, data, combined_features):
+        if self.optimizer is None:
+            self.compile()
+        if getattr(self, '_graph_mode', False):
+            return self._train_step_graphed(data, combined_features)
+        out, _ = self.loss_and_grads(data, combined_features)
+        self._clip_and_step()
         return out
+
+    # -- the step as one HIP graph (compile(graph=True)) --
+    _GRAPH_INPUTS = ('translations_landscape', 'rotations_landscape', 'translations_grad', 'rotations_grad', 'src_images', 'src_intrinsics',
+                     'src_extrinsics_inv', 'combined_features', 'label_landscape', 'label_grad_t', 'label_grad_r')
+
+    def graph_inputs(self):
+        """name -> the device buffer the captured step reads (None before the first step)."""
+        return None if self._g_static is None else dict(zip(self._GRAPH_INPUTS, self._g_static))
+
+    def bind_graph_inputs(self, data, combined_features):
+        """Make the caller's own device tensors (fp32, contiguous) the buffers of the captured step: whatever they hold at the time of a
+        `train_step` is what that step reads, nothing is copied (2.5 GB of features at the cfg3 shape).  Before the capture only."""
+        if self._graph is not None:
+            raise RuntimeError('the step is already captured; call compile(graph=True) again first')
+        inputs, labels = data
+        flat = [*inputs[:7], combined_features, *labels]
+        for name, t in zip(self._GRAPH_INPUTS, flat):
+            if not (isinstance(t, torch.Tensor) and t.device == self.device_ and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError(f'{name}: bind_graph_inputs wants contiguous float32 tensors on {self.device_}')
+        self._g_static = flat
+
+    def _stage(self, data, combined_features):
+        inputs, labels = data
+        flat = [torch.as_tensor(x, dtype=torch.float32) for x in (*inputs[:7], combined_features, *labels)]
+        if self._g_static is None:
+            self._g_static = [torch.empty(t.shape, dtype=torch.float32, device=self.device_) for t in flat]
+        for t, s in zip(flat, self._g_static):
+            if t.shape != s.shape:
+                raise ValueError(f'compile(graph=True) fixed the input shapes at the first step: got {tuple(t.shape)}, captured '
+                                 f'{tuple(s.shape)}; call compile(graph=True) again for a new shape')
+            if not (t.device == s.device and t.data_ptr() == s.data_ptr()):
+                s.copy_(t, non_blocking=True)
+        st = self._g_static
+        return (tuple(st[:7]), tuple(st[8:])), st[7]
+
+    def _train_step_graphed(self, data, combined_features):
+        data_s, feats = self._stage(data, combined_features)
+        if self._g_calls < 2:
+            self._g_calls += 1
+            side = torch.cuda.Stream(self.device_)
+            side.wait_stream(torch.cuda.current_stream(self.device_))
+            with torch.cuda.stream(side):
+                out, _ = self.loss_and_grads(data_s, feats)
+                self._clip_and_step()
+            torch.cuda.current_stream(self.device_).wait_stream(side)
+            return out
+        if self._graph is None:
+            torch.cuda.synchronize(self.device_)
+            for prm in self.grasp_readout.parameters():
+                prm.grad = None
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out, _ = self.loss_and_grads(data_s, feats)
+                self._clip_and_step()
+            self._graph, self._g_out = graph, out
+        self._graph.replay()
+        return {k: v.clone() for k, v in self._g_out.items()}
