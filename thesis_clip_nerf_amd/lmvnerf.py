@@ -295,6 +295,7 @@ class LanguageNeRF(nn.Module):
         self.pose_variables = [self.translations, self.rotations]
         self.loss = kl_divergence if softmax_before_loss else None
         self.optimizer = None
+        self._graph_mode, self._graph, self._g_static, self._g_out, self._g_calls = False, None, None, None, 0
         self.to(self.device_)
 
     # -- reference API --
@@ -399,7 +400,7 @@ class LanguageNeRF(nn.Module):
     def train_step(self, data, combined_features):
         if self.optimizer is None:
             self.compile()
-        if getattr(self, '_graph_mode', False):
+        if self._graph_mode:
             return self._train_step_graphed(data, combined_features)
         out, _ = self.loss_and_grads(data, combined_features)
         self._clip_and_step()
