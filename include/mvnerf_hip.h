@@ -333,6 +333,11 @@ int mvnerf_query_vjp(const float* points, const float* dirs, const float* images
                      const float* g_acts, int B, int V, int N, int H, int W, void* scratch, float* d_points, float* d_dirs,
                      mvnerf_stream_t stream);
 
+/* The four fused activations (view mean, u1, u2, u3 - layers.py:376-377, what LanguageNeRF._call keeps as outputs[4:],
+ * lmvnerf/model_v4.py:261-262) of a stash written by mvnerf_field_eval_stash with R = N, S = 1, as row-major acts (4, B*N, 128):
+ * the stash holds them in the tile layout [tile][feature][32 points]; one transposing pass through LDS.  acts 16-byte aligned. */
+int mvnerf_stash_fused_acts(const float* stash, int B, int V, int N, float* acts, mvnerf_stream_t stream);
+
 /* optimize(): clip-by-value (clip > 0) then one Adam step with the bias-corrected rate lr_t.
  * update_mask (optional): n bytes, 0 = leave the element untouched. */
 int mvnerf_adam_clip(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1, float beta2,

@@ -234,3 +234,27 @@ def test_language_train_step_graph_replay_matches_eager():
         graphed.train_step(((*[a[:, :2] for a in inputs[:4]], *inputs[4:]), labels), sc['features'])
     with pytest.raises(RuntimeError):
         graphed.bind_graph_inputs(datas[0], sc['features'])
+
+
+@pytest.mark.parametrize('n_views,n_points,batch', [(1, 40, 2), (2, 64, 2), (1, 33, 1)])
+def test_stash_fused_acts_is_the_transposed_stash(n_views, n_points, batch):
+    """mvnerf_stash_fused_acts against the same gather written with torch views of the stash (bit-exact: it only moves floats), and against
+    the acts_fused output of the plain field pass."""
+    sc = make_scene(seed=80 + n_points, batch=batch, n_views=n_views, height=16, width=20, n_rays=4)
+    rng = np.random.default_rng(n_points)
+    points = (np.array([0.0, 0.0, 0.8]) + 0.1 * rng.standard_normal((batch, n_points, 3))).astype(np.float32)
+    dirs = rng.standard_normal((batch, n_points, 3)).astype(np.float32)
+    d = {k: dev(sc[k]) for k in ('images', 'features', 'intrinsics', 'extrinsics_inv', 'fine')}
+    geo = (d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'])
+    packed = ops.pack_net(d['fine'])
+    stash = ops.query_stash(dev(points), dev(dirs), *geo, packed)
+    acts = ops.stash_fused_acts(stash, batch, n_views, n_points)
+    rows = batch * n_points
+    tiles = (rows + 31) // 32
+    fused = stash.view(torch.float32)[7 * n_views * tiles * 4096:][:7 * tiles * 4096].view(7, tiles, 128, 32)
+    ref = fused[0::2].permute(0, 1, 3, 2).reshape(4, tiles * 32, 128)[:, :rows].reshape(4, batch, n_points, 128)
+    assert torch.equal(acts, ref)
+    direct = torch.stack(ops.query_field(dev(points), dev(dirs), *geo, packed, complete_output=True)[1][4:])
+    assert (acts - direct).abs().max().item() < 1e-5 * max(1.0, direct.abs().max().item())
+    with pytest.raises(ValueError):
+        ops.stash_fused_acts(stash[:1024], batch, n_views, n_points)

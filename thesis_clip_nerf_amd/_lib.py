@@ -32,6 +32,7 @@ SIGNATURES = {
     'mvnerf_query_jvp': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p] * 4),
     'mvnerf_query_vjp_scratch_bytes': (c_size_t, [c_int] * 3),
     'mvnerf_query_vjp': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p] * 4),
+    'mvnerf_stash_fused_acts': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'mvnerf_texel_table_bytes': (c_size_t, [c_int] * 4),
     'mvnerf_project_texels': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
     'mvnerf_project_texels2': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 3),

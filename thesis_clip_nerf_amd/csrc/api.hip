@@ -672,6 +672,17 @@ int mvnerf_query_vjp(const float* points, const float* dirs, const float* images
     return 0;
 }
 
+int mvnerf_stash_fused_acts(const float* stash, int B, int V, int N, float* acts, mvnerf_stream_t stream) {
+    if (!stash || !acts) return fail(MVNERF_E_ARG, "mvnerf_stash_fused_acts: null pointer");
+    if (B <= 0 || V <= 0 || N <= 0) return fail(MVNERF_E_ARG, "mvnerf_stash_fused_acts: B=%d V=%d N=%d", B, V, N);
+    if (!aligned16(stash) || !aligned16(acts)) return fail(MVNERF_E_ALIGN, "mvnerf_stash_fused_acts: stash, acts must be 16-byte aligned");
+    const long total = (long)B * N, n_tiles = (total + 31) / 32;
+    const size_t vslot = (size_t)n_tiles * V * 4096, fslot = (size_t)n_tiles * 4096;
+    // fused slots 0, 2, 4, 6 = view mean, u1, u2, u3 (the odd ones are the blocks' hidden pre-activations)
+    return hip_status(mvnerf::launch_tl_to_rows(stash + 7 * vslot, (long)(2 * fslot), 4, total, n_tiles, acts, static_cast<hipStream_t>(stream)),
+                      "mvnerf_stash_fused_acts");
+}
+
 int mvnerf_adam_clip(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1, float beta2,
                      float eps, float clip, const unsigned char* update_mask, mvnerf_stream_t stream) {
     if (!param || !grad || !m || !v) return fail(MVNERF_E_ARG, "mvnerf_adam_clip: null pointer");

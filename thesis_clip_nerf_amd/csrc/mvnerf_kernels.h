@@ -92,6 +92,8 @@ hipError_t launch_texel_grad_to_features(const float* texel_grad, const float* w
 // Zero `bytes` (a multiple of 4, dword-aligned) with a kernel.  Used instead of hipMemsetAsync: a memset node captured into a HIP graph from
 // the autograd thread did not run on the graph's later launches (ROCm 7.2; LanguageNeRF.compile(graph=True) replays these paths).
 hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t st);
+// rows (n_slots, n_rows, 128) row-major <- n_slots tile-layout tensors `slot_stride` floats apart (tile = 128 features x 32 rows)
+hipError_t launch_tl_to_rows(const float* tl, long slot_stride, int n_slots, long n_rows, long n_tiles, float* rows, hipStream_t st);
 hipError_t launch_rows_to_tl(const float* rows, long n_rows, long n_tiles, int accumulate, float* out_tl, hipStream_t st);
 hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int g_feats, long n_tiles, float* dW, int ldn,
                           int n_valid, float* db, int max_wgs, float* part, hipStream_t st);

@@ -969,6 +969,34 @@ hipError_t launch_rows_to_tl(const float* rows, long n_rows, long n_tiles, int a
     return hipGetLastError();
 }
 
+// ---- tile layout -> (rows,128) row-major: the fused activations of a query stash for the GraspReadout ----
+// One workgroup per (tile, slot): the tile's 128 x 32 floats go through LDS (pitch 33: the transposed reads are conflict-free), both the
+// global reads and the global writes are full 256-byte rows per wave instruction.
+__global__ __launch_bounds__(256) void tl_to_rows_kernel(const float* __restrict__ tl, long slot_stride, long n_rows, float* __restrict__ rows) {
+    __shared__ float t[128 * 33];
+    const long tile = blockIdx.x;
+    const int slot = blockIdx.y, tid = threadIdx.x;
+    const float* src = tl + (size_t)slot * slot_stride + tile * 4096;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = i * 256 + tid;
+        t[(e >> 5) * 33 + (e & 31)] = src[e];
+    }
+    __syncthreads();
+    float* dst = rows + ((size_t)slot * n_rows + tile * 32) * 128;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = i * 256 + tid, r = e >> 7, k = e & 127;
+        if (tile * 32 + r < n_rows) dst[(size_t)r * 128 + k] = t[k * 33 + r];
+    }
+}
+
+hipError_t launch_tl_to_rows(const float* tl, long slot_stride, int n_slots, long n_rows, long n_tiles, float* rows, hipStream_t st) {
+    if (n_tiles <= 0 || n_tiles > 0x7fffffffL || n_slots <= 0 || n_slots > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tl_to_rows_kernel, dim3((unsigned)n_tiles, (unsigned)n_slots), dim3(256), 0, st, tl, slot_stride, n_rows, rows);
+    return hipGetLastError();
+}
+
 // Row r of the (B*V*R*S)-row per-view tensors -> batch-view index, global ray, global sample index.
 struct ViewRow {
     int bv, b, ray;

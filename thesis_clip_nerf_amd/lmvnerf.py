@@ -68,13 +68,10 @@ class TrunkField(torch.autograd.Function):
         pad = (-n) % 32 if state.n_views > 1 else 0     # the multi-view training kernels want whole 32-point tiles per scene
         p, d = _pad32(points.detach().contiguous(), pad), _pad32(dirs.detach().contiguous(), pad)
         stash = ops.query_stash(p, d, *state.geo, state.packed, packed_split=state.packed_split)
-        rows = b * (n + pad)
-        tiles = (rows + 31) // 32
-        fused = stash.view(torch.float32)[7 * state.n_views * tiles * 4096:][:7 * tiles * 4096].view(7, tiles, 128, 32)
-        acts = fused[0::2].permute(0, 1, 3, 2).reshape(4, tiles * 32, 128)[:, :rows].reshape(4, b, n + pad, 128)
+        acts = ops.stash_fused_acts(stash, b, state.n_views, n + pad)       # tile layout -> (4, b, n + pad, 128) rows
         ctx.state, ctx.stash, ctx.pad, ctx.n = state, stash, pad, n
         ctx.save_for_backward(p, d)
-        return acts[:, :, :n].contiguous()
+        return acts[:, :, :n].contiguous() if pad else acts
 
     @staticmethod
     def backward(ctx, g_acts):

@@ -806,6 +806,18 @@ def query_stash(points, dirs, images, features, intrinsics, extrinsics_inv, pack
     return field_eval_stash(points, dirs, z, images, features, intrinsics, extrinsics_inv, packed_net, stash, packed_split=packed_split)[1]
 
 
+def stash_fused_acts(stash, b, v, n):
+    """mvnerf_stash_fused_acts: the four fused activations of a query stash (query_stash on (b, n) points, v views) as (4, b, n, 128)."""
+    _chk(stash, 'stash', dtype=torch.uint8)
+    if stash.numel() < stash_bytes(b, v, n, 1):
+        raise ValueError(f'stash: {stash.numel()} bytes, need {stash_bytes(b, v, n, 1)}')
+    acts = torch.empty((4, b, n, 128), dtype=torch.float32, device=stash.device)
+    with torch.cuda.device(stash.device):
+        rc = _lib.lib().mvnerf_stash_fused_acts(_p(stash), b, v, n, _p(acts), _stream(stash))
+    _lib.check(rc, 'stash_fused_acts')
+    return acts
+
+
 def query_vjp(points, dirs, images, features, intrinsics, extrinsics_inv, bwd_streams, stash, g_acts):
     """mvnerf_query_vjp: cotangents (4,B,N,128) of the four fused activations -> (d_points, d_dirs), each (B,N,3)."""
     b, v, n, h, w = _query_shapes(points, dirs, images, features, intrinsics, extrinsics_inv)
