@@ -301,6 +301,10 @@ int mvnerf_field_backward_table(const float* rays_o, const float* rays_d, const 
  * scratch: mvnerf_gemm_nt_scratch_bytes(M,N,K) bytes (0 for shapes that are not split: NULL allowed). */
 size_t mvnerf_gemm_nt_scratch_bytes(int M, int N, int K);
 int mvnerf_gemm_nt(const float* a, const float* bt, float* c, int M, int N, int K, void* scratch, mvnerf_stream_t stream);
+/* The Dense layer itself, c = a bt^T + bias (bias: N floats, added after the products - the result equals mvnerf_gemm_nt followed by a
+ * broadcast add, bit for bit, in one launch less). */
+int mvnerf_gemm_nt_bias(const float* a, const float* bt, const float* bias, float* c, int M, int N, int K, void* scratch,
+                        mvnerf_stream_t stream);
 
 /* c (N,K) = g (M,N)^T . a (M,K): the weight gradient of a Dense layer with both operands as they lie (rows = the M samples that are
  * contracted), same kernel family and determinism as mvnerf_gemm_nt.  M % 8 == 0, N % 32 == 0, K % 64 == 0;

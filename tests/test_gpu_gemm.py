@@ -32,6 +32,17 @@ def test_gemm_tn_matches_float64(m, n, k):
     assert torch.equal(got, ops.gemm_tn(gm.to(DEV), a.to(DEV)).cpu().double())
 
 
+@pytest.mark.parametrize('m,n,k', [(64512, 64, 128), (96, 128, 2688), (32, 64, 8)])
+def test_gemm_nt_bias_equals_the_product_plus_a_broadcast_add(m, n, k):
+    """mvnerf_gemm_nt_bias adds the bias after the products (epilogue of the unsplit kernel / of the split-K reduce): bit for bit the
+    unfused result.  (64512, 64, 128) is the unsplit case, (96, 128, 2688) the split one."""
+    g = torch.Generator().manual_seed(m + n + k + 1)
+    a, bt, b = (torch.randn(sh, generator=g).to(DEV) for sh in ((m, k), (n, k), (n,)))
+    assert torch.equal(ops.gemm_nt(a, bt, bias=b), ops.gemm_nt(a, bt) + b)
+    with pytest.raises(ValueError):
+        ops.gemm_nt(a, bt, bias=b[:-1].contiguous())
+
+
 def test_gemm_nt_rejects_other_shapes():
     a = torch.zeros((30, 8), device=DEV)
     with pytest.raises(ValueError, match='needs M'):

@@ -71,6 +71,7 @@ SIGNATURES = {
     'mvnerf_gemm_tn_scratch_bytes': (c_size_t, [c_int] * 3),
     'mvnerf_gemm_tn': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p] * 2),
     'mvnerf_gemm_nt': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p] * 2),
+    'mvnerf_gemm_nt_bias': (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 2),
     'mvnerf_field_backward_table': (c_int, [c_void_p] * 14 + [c_int] * 6 + [c_void_p] * 5),
     'mvnerf_adam_clip': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float,
                                  c_void_p, c_void_p]),

@@ -554,15 +554,25 @@ size_t mvnerf_gemm_nt_scratch_bytes(int M, int N, int K) {
     return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
 
-int mvnerf_gemm_nt(const float* a, const float* bt, float* c, int M, int N, int K, void* scratch, mvnerf_stream_t stream) {
-    if (!a || !bt || !c) return fail(MVNERF_E_ARG, "mvnerf_gemm_nt: null pointer");
+static int gemm_nt_impl(const char* who, const float* a, const float* bt, const float* bias, float* c, int M, int N, int K, void* scratch,
+                        mvnerf_stream_t stream) {
+    if (!a || !bt || !c) return fail(MVNERF_E_ARG, "%s: null pointer", who);
     if (!gemm_nt_shape_ok(M, N, K))
-        return fail(MVNERF_E_SHAPE, "mvnerf_gemm_nt: M=%d N=%d K=%d, needs M %% 32 == 0, N %% 64 == 0, K %% 8 == 0", M, N, K);
-    if (!aligned16(a) || !aligned16(bt) || !aligned16(c) || (scratch && !aligned16(scratch)))
-        return fail(MVNERF_E_ALIGN, "mvnerf_gemm_nt: a, bt, c, scratch must be 16-byte aligned");
-    if (mvnerf_gemm_nt_scratch_bytes(M, N, K) && !scratch) return fail(MVNERF_E_ARG, "mvnerf_gemm_nt: this shape needs scratch");
-    return hip_status(mvnerf::launch_gemm_nt_f32(a, bt, c, M, N, K, static_cast<float*>(scratch), static_cast<hipStream_t>(stream)),
-                      "mvnerf_gemm_nt");
+        return fail(MVNERF_E_SHAPE, "%s: M=%d N=%d K=%d, needs M %% 32 == 0, N %% 64 == 0, K %% 8 == 0", who, M, N, K);
+    if (!aligned16(a) || !aligned16(bt) || !aligned16(c) || (scratch && !aligned16(scratch)) || (bias && !aligned16(bias)))
+        return fail(MVNERF_E_ALIGN, "%s: a, bt, bias, c, scratch must be 16-byte aligned", who);
+    if (mvnerf_gemm_nt_scratch_bytes(M, N, K) && !scratch) return fail(MVNERF_E_ARG, "%s: this shape needs scratch", who);
+    return hip_status(mvnerf::launch_gemm_nt_f32(a, bt, bias, c, M, N, K, static_cast<float*>(scratch), static_cast<hipStream_t>(stream)), who);
+}
+
+int mvnerf_gemm_nt(const float* a, const float* bt, float* c, int M, int N, int K, void* scratch, mvnerf_stream_t stream) {
+    return gemm_nt_impl("mvnerf_gemm_nt", a, bt, nullptr, c, M, N, K, scratch, stream);
+}
+
+int mvnerf_gemm_nt_bias(const float* a, const float* bt, const float* bias, float* c, int M, int N, int K, void* scratch,
+                        mvnerf_stream_t stream) {
+    if (!bias) return fail(MVNERF_E_ARG, "mvnerf_gemm_nt_bias: null pointer");
+    return gemm_nt_impl("mvnerf_gemm_nt_bias", a, bt, bias, c, M, N, K, scratch, stream);
 }
 
 static bool gemm_tn_shape_ok(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && M % 8 == 0 && N % 32 == 0 && K % 64 == 0; }

@@ -18,7 +18,7 @@
 namespace mvnerf {
 
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bt, float* __restrict__ C,
-                                                          int M, int N, int K, int splits) {
+                                                          int M, int N, int K, int splits, const float* __restrict__ bias) {
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int tiles_n = N / 64;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -56,18 +56,21 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
         q4 = qn;
     }
     const int col = lane & 31, hh = lane >> 5;
+    // Dense bias (x W^T + b, added after the products like the separate add it replaces); with K split it is added by the reduce instead
+    const float bias0 = (bias && splits == 1) ? bias[64 * tn + col] : 0.0f, bias1 = (bias && splits == 1) ? bias[64 * tn + 32 + col] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float* crow = C + (long)(32 * tm + acc_row(r, hh)) * N + 64 * tn + col;
-        crow[0] = acc0[r];
-        crow[32] = acc1[r];
+        crow[0] = acc0[r] + bias0;
+        crow[32] = acc1[r] + bias1;
     }
 }
 
 // c[i] = sum over the splits' partials in a fixed order: a 64 x 16 block takes 64 float4 elements, thread (x, y) adds the partials
 // y, y + 16, ... with two independent chains, the 16 sums are added in y order through LDS (a serial walk over 1024 partials
 // per element took 100 us)
-__global__ __launch_bounds__(1024) void gemm_reduce_kernel(const f32x4* __restrict__ part, long n4, int splits, f32x4* __restrict__ c) {
+__global__ __launch_bounds__(1024) void gemm_reduce_kernel(const f32x4* __restrict__ part, long n4, int splits, f32x4* __restrict__ c,
+                                                           const f32x4* __restrict__ bias4, int n_cols4) {
     __shared__ f32x4 sred[16][64];
     const int x = threadIdx.x, y = threadIdx.y;
     const long i = (long)blockIdx.x * 64 + x;
@@ -97,6 +100,11 @@ __global__ __launch_bounds__(1024) void gemm_reduce_kernel(const f32x4* __restri
         for (int q = 1; q < 16; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[e] = s[e] + sred[q][x][e];
+        if (bias4) {                                          // row-major (rows, 4 n_cols4) output: element i sits in columns 4 (i % n_cols4) ..
+            const f32x4 b = bias4[i % n_cols4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = s[e] + b[e];
+        }
         c[i] = s;
     }
 }
@@ -113,16 +121,16 @@ int gemm_nt_splits(int M, int N, int K) {
     return want < 1 ? 1 : (int)want;
 }
 
-hipError_t launch_gemm_nt_f32(const float* A, const float* Bt, float* C, int M, int N, int K, float* scratch, hipStream_t st) {
+hipError_t launch_gemm_nt_f32(const float* A, const float* Bt, const float* bias, float* C, int M, int N, int K, float* scratch, hipStream_t st) {
     const int tiles = (M / 32) * (N / 64), splits = gemm_nt_splits(M, N, K);
     if (splits > 1 && !scratch) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3((unsigned)((tiles + 3) / 4), (unsigned)splits), dim3(256), 0, st, A, Bt, splits > 1 ? scratch : C,
-                       M, N, K, splits);
+                       M, N, K, splits, bias);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || splits == 1) return e;
     const long n4 = (long)M * N / 4;
     hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64, 16), 0, st, reinterpret_cast<const f32x4*>(scratch), n4, splits,
-                       reinterpret_cast<f32x4*>(C));
+                       reinterpret_cast<f32x4*>(C), reinterpret_cast<const f32x4*>(bias), N / 4);
     return hipGetLastError();
 }
 
@@ -199,7 +207,7 @@ hipError_t launch_gemm_tn_f32(const float* G, const float* A, float* C, int M, i
     if (e != hipSuccess || splits == 1) return e;
     const long n4 = (long)N * K / 4;
     hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64, 16), 0, st, reinterpret_cast<const f32x4*>(scratch), n4, splits,
-                       reinterpret_cast<f32x4*>(C));
+                       reinterpret_cast<f32x4*>(C), static_cast<const f32x4*>(nullptr), 1);
     return hipGetLastError();
 }
 

@@ -80,7 +80,8 @@ hipError_t launch_finish_view(const float* rgb, const float* depth, long n, floa
                               hipStream_t st);
 
 // train_ops.hip
-hipError_t launch_gemm_nt_f32(const float* A, const float* Bt, float* C, int M, int N, int K, float* scratch, hipStream_t st);
+hipError_t launch_gemm_nt_f32(const float* A, const float* Bt, const float* bias, float* C, int M, int N, int K, float* scratch,
+                              hipStream_t st);   // bias: N floats added to every row, or nullptr
 int gemm_nt_splits(int M, int N, int K);
 hipError_t launch_gemm_tn_f32(const float* G, const float* A, float* C, int M, int N, int K, float* scratch, hipStream_t st);
 int gemm_tn_splits(int M, int N, int K);

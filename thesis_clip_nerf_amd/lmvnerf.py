@@ -136,6 +136,24 @@ class _MatmulTN(torch.autograd.Function):
         return gg, ga
 
 
+class _LinearNT(torch.autograd.Function):
+    """x (M,K) @ w (N,K)^T + b with the bias added in the GEMM's epilogue (mvnerf_gemm_nt_bias: one launch instead of two).  The backward is
+    _MatmulNT / _MatmulTN and a column sum, so it can be differentiated again like the unfused form."""
+
+    @staticmethod
+    def forward(ctx, a, w, b):
+        ctx.save_for_backward(a, w)
+        return ops.gemm_nt(a.contiguous(), w.contiguous(), bias=b.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, w = ctx.saved_tensors
+        ga = _MatmulNT.apply(g, w.t()) if ctx.needs_input_grad[0] else None
+        gw = _MatmulTN.apply(g, a) if ctx.needs_input_grad[1] else None
+        gb = g.sum(0) if ctx.needs_input_grad[2] else None
+        return ga, gw, gb
+
+
 def _mm_nt(a, bt):
     """a @ bt^T through _MatmulNT on the GPU (fp32), plain torch otherwise."""
     if a.is_cuda and a.dtype == torch.float32 and bt.dtype == torch.float32:
@@ -147,9 +165,13 @@ def _wide_linear(lin, x):
     """nn.Linear through _mm_nt (value, input / weight gradients and their derivatives)."""
     if not x.is_cuda:
         return lin(x)
-    y = _mm_nt(x.reshape(-1, lin.in_features), lin.weight)
-    if lin.bias is not None:
-        y = y + lin.bias
+    x2 = x.reshape(-1, lin.in_features)
+    if lin.bias is not None and x2.dtype == torch.float32 and _skinny(x2.shape[0], lin.out_features, lin.in_features):
+        y = _LinearNT.apply(x2, lin.weight, lin.bias)
+    else:
+        y = _mm_nt(x2, lin.weight)
+        if lin.bias is not None:
+            y = y + lin.bias
     return y.reshape(*x.shape[:-1], lin.out_features)
 
 

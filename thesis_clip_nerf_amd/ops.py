@@ -550,17 +550,23 @@ def gemm_nt_ok(m, n, k):
     return m > 0 and n > 0 and k > 0 and m % 32 == 0 and n % 64 == 0 and k % 8 == 0
 
 
-def gemm_nt(a, bt):
-    """mvnerf_gemm_nt: a (M,K) @ bt (N,K)^T -> (M,N), fp32, deterministic (K split into ranges whose partials are added in order)."""
+def gemm_nt(a, bt, bias=None):
+    """mvnerf_gemm_nt / mvnerf_gemm_nt_bias: a (M,K) @ bt (N,K)^T [+ bias (N,)] -> (M,N), fp32, deterministic (K split into ranges whose
+    partials are added in order)."""
     m, k = a.shape
     n = bt.shape[0]
     _chk(a, 'a', shape=(m, k))
     _chk(bt, 'bt', shape=(n, k))
+    if bias is not None:
+        _chk(bias, 'bias', shape=(n,))
     out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     need = int(_lib.lib().mvnerf_gemm_nt_scratch_bytes(m, n, k))
     scratch = torch.empty(need, dtype=torch.uint8, device=a.device) if need else None
     with torch.cuda.device(a.device):
-        rc = _lib.lib().mvnerf_gemm_nt(_p(a), _p(bt), _p(out), m, n, k, _p(scratch), _stream(a))
+        if bias is None:
+            rc = _lib.lib().mvnerf_gemm_nt(_p(a), _p(bt), _p(out), m, n, k, _p(scratch), _stream(a))
+        else:
+            rc = _lib.lib().mvnerf_gemm_nt_bias(_p(a), _p(bt), _p(bias), _p(out), m, n, k, _p(scratch), _stream(a))
     _lib.check(rc, 'gemm_nt')
     return out
 
