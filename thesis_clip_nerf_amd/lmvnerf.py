@@ -319,8 +319,9 @@ class LanguageNeRF(nn.Module):
 
     # -- reference API --
     def compile(self, optimizer=None, loss=None, learning_rate=1e-4, graph=False):
-        """graph=True: `train_step` is captured ONCE as a HIP graph (torch.cuda.CUDAGraph) and replayed: the step is ~400 launches of
-        3-500 us, a third of its wall time is launch latency (profiles/r02_language_step_trace.md).  The graph fixes shapes and addresses:
+        """graph=True: `train_step` is captured ONCE as a HIP graph (torch.cuda.CUDAGraph) and replayed: the step is ~740 launches of
+        3-500 us that the host cannot issue as fast as the GPU runs them - 6.6 ms per replay against 8-10.7 ms eager at the cfg3 shape
+        (profiles/r02_language_step_graph.md).  The graph fixes shapes and addresses:
         inputs are staged into the buffers `graph_inputs()` returns (a producer that writes `combined_features` there in place skips the
         copy), the optimizer is this method's own Adam (capturable).  The first two steps run eagerly (they load every kernel and size
         the allocator pools), the third is captured."""
