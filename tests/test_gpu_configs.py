@@ -51,6 +51,7 @@ def big_scene(seed, batch, n_views, height, width, n_rays, bias_scale=0.0):
 def cfg5():
     sc, d = big_scene(seed=21, batch=1, n_views=3, height=480, width=640, n_rays=16384)
     d['pc'], d['pf'] = ops.pack_net(d['coarse']), ops.pack_net(d['fine'])
+    d['split'] = (ops.pack_net_split(d['coarse']), ops.pack_net_split(d['fine']))
     d['pc16'], d['pf16'] = ops.pack_net_bf16(d['coarse']), ops.pack_net_bf16(d['fine'])
     sub = np.arange(0, 16384, 64)                                           # 256 rays, strided over the whole batch
     sc['features'] = d['features'].cpu().numpy()
@@ -61,45 +62,59 @@ def cfg5():
     del sc['features']
 
 
-def _render(d, sl=slice(None), tables='auto'):
+GEMMS = ['split_bf16', 'mfma_f32']      # the two fp32 field kernels (MVVNeRFRenderer(f32_gemm=...)); the default, which bench.py times, first
+
+
+def _render(d, sl=slice(None), tables='auto', gemm='split_bf16'):
     pick = lambda t: t[:, sl].contiguous()
     return ops.render_fwd(pick(d['rays_o']), pick(d['rays_d']), d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'],
-                          d['pc'], d['pf'], pick(d['u_coarse']), pick(d['u_fine']), d['near'], d['far'], texel_tables=tables)
+                          d['pc'], d['pf'], pick(d['u_coarse']), pick(d['u_fine']), d['near'], d['far'], texel_tables=tables,
+                          split=d['split'] if gemm == 'split_bf16' else None)
 
 
-def test_cfg5_fp32_render_matches_oracle_and_is_ray_independent(cfg5):
+@pytest.mark.parametrize('gemm', GEMMS)
+def test_cfg5_fp32_render_matches_oracle_and_is_ray_independent(cfg5, gemm):
     sc, d, sub, ref = cfg5
     assert d['features'].numel() * 4 > 900e6                                # 944 MB of feature maps, 2 x 472 MB of texel tables
     assert ops.texel_table_pays(16384, 64, 480, 640)
-    whole = _render(d, tables='auto')
-    direct = _render(d, tables=None)
+    _render_g = lambda d_, sl=slice(None), tables='auto': _render(d_, sl, tables, gemm)
+    whole = _render_g(d, tables='auto')
+    direct = _render_g(d, tables=None)
     torch.cuda.synchronize()
     names = ['rgb', 'depth', 'fine_rgb', 'fine_depth']
     for name, got_t, got_d, want in zip(names, whole, direct, ref[:4]):
         for tag, got in (('table', got_t), ('direct', got_d)):
             err = float(np.abs(got[:, sub].cpu().numpy() - want).max())
-            print(f'cfg5 fp32 {tag} {name}: max|hip - oracle| over 256 rays = {err:.2e}')
-            assert err < 1e-4, (name, tag, err)                              # north_star: rendered RGB within 1e-4 in fp32
+            print(f'cfg5 fp32 {gemm} {tag} {name}: max|hip - oracle| over 256 rays = {err:.2e}')
+            assert err < 1e-4, (name, gemm, tag, err)                              # north_star: rendered RGB within 1e-4 in fp32
         assert (got_t - got_d).abs().max().item() < 2e-5, name              # fp32 re-association of layer 0 only
     # determinism and ray independence (the cut leaves a ragged 32-sample tile), on the direct path and on the table path - the
     # latter with the tables forced, since 'auto' would build none for the smaller part (R*S < 2*H*W there)
     forced = torch.empty((2, 1, 3, 480, 640, 128), dtype=torch.float32, device=DEV)
     for tables, ref_out in ((None, direct), (forced, whole)):
-        again = _render(d, tables=tables)
-        lo, hi = _render(d, slice(0, 5001), tables), _render(d, slice(5001, 16384), tables)
+        again = _render_g(d, tables=tables)
+        lo, hi = _render_g(d, slice(0, 5001), tables), _render_g(d, slice(5001, 16384), tables)
         for w_, a_, l_, h_ in zip(ref_out, again, lo, hi):
             assert torch.equal(w_, a_)                                      # deterministic
             assert torch.equal(w_, torch.cat([l_, h_], 1))                  # rays are independent units
 
 
-def test_cfg5_tap_indices_and_sample_indices_bit_exact(cfg5):
+@pytest.mark.parametrize('gemm', GEMMS)
+def test_cfg5_tap_indices_and_sample_indices_bit_exact(cfg5, gemm):
     sc, d, sub, ref = cfg5
     aux = ref[4]
     sub_t = torch.from_numpy(sub).to(DEV)
     z = ops.stratified_depths(d['u_coarse'], d['near'], d['far'])
     np.testing.assert_array_equal(z[:, sub_t].cpu().numpy(), aux['z'])      # fp32, identical bits
     geo = (d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'])
-    rgbs_c, taps_c = ops.field_eval(d['rays_o'], d['rays_d'], z, *geo, d['pc'], return_taps=True)
+    if gemm == 'split_bf16':
+        rgbs_c, taps_c = ops.field_eval_split(d['rays_o'], d['rays_d'], z, *geo, d['pc'], d['split'][0], return_taps=True)
+    else:
+        rgbs_c, taps_c = ops.field_eval(d['rays_o'], d['rays_d'], z, *geo, d['pc'], return_taps=True)
+    # per-sample (rgb, sigma) of the coarse pass on the strided rays against the oracle's (direct gather)
+    got_rgbs = rgbs_c[:, sub_t].cpu().numpy()
+    assert np.abs(got_rgbs[..., :3] - aux['coarse_rgb']).max() < 2e-5
+    assert np.abs(got_rgbs[..., 3] - aux['coarse_sigma']).max() < 5e-5
     net = O.unflatten_net(sc['coarse'])
     _, _, taps_ref = O.field_eval(net, sc['rays_o'][:, sub], sc['rays_d'][:, sub], aux['z'], sc['images'], sc['features'],
                                   sc['intrinsics'], sc['extrinsics_inv'], return_taps=True)
