@@ -15,15 +15,23 @@ B=1 scene, V=1 source view of 64x64 (3+256 channels), R=4096 rays (every pixel o
 view), fp32, inputs resident in HBM before the timed region.  N>1: every rank renders its own
 scene (rays/scenes are independent units, no data-path collective) -> weak scaling.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (field_eval_kernel, fp32 MFMA bound): the FLOPs the
-launch EXECUTES on the matrix pipe (tiles x MFMAs per 32-sample tile x 4096 FLOP per v_mfma_f32_32x32x2_f32; the count
-is checked against SQ_INSTS_VALU_MFMA_MOPS_F32 in profiles/) / its average duration measured with HIP events inside the
-timed region, against the 157.3 TFLOP/s fp32 MFMA peak; SURVEY.md 8d's algorithmic figure (491 264 FLOP/sample) over the
-same duration is reported beside it as `frac_reference_equiv`.  `cpu_baseline` times the op-for-op torch-CPU restatement
-of the reference's TF graph (oracle/mvnerf_torch.py, fp32; the reference itself cannot run here) on all 4096 rays on the
-host cores; `parity` checks the GPU result against the NumPy oracle on all 4096 rays.  `train_cfg4` is the data-parallel
-training leg (BASELINE.json configs[3]): one 128x128 scene = 16 384 rays per GPU, forward with stash + backward + ONE
-flat all-reduce of the 494 600 gradients + clip + Adam.
+`--scaling strong` (SURVEY.md 8d cfg4, strong leg): ONE fixed job - the 16 384 rays of a 128x128 scene - split over the N ranks by
+`distributed.shard_bounds` (contiguous ray blocks, replicated weights and source view, no data-path collective); `value` is then
+16 384 x K / time and `scaling` reads "strong".  The default (and what the driver runs) is the weak leg above.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the fine-pass launch of the field kernel.  Default
+(`--f32-gemm split_bf16`): `field_eval_split_kernel` - fp32 operands cut exactly into three bf16 pieces, six
+v_mfma_f32_32x32x16_bf16 per product block, fp32 accumulation - so the pipe it is bound by is the bf16 matrix pipe:
+`peak` = 2 500 TFLOP/s dense bf16 (`peak_dtype`), `achieved` / `frac` = `frac_executed` count the FLOPs the launch EXECUTES there
+(tiles x MFMAs per 32-sample tile x 32 768 FLOP per MFMA; the count is checked against SQ_INSTS_MFMA in profiles/), and
+`frac_algorithmic` restates the same duration in SURVEY.md 8d's algorithmic figure (491 264 FLOP per sample at V = 1) against the
+same peak - 5.1x lower, the price of fp32-grade products on a bf16 pipe.  `--f32-gemm mfma_f32` times `field_eval_kernel` on the
+fp32 MFMA (v_mfma_f32_32x32x2_f32, 4 096 FLOP each, peak 157.3 TFLOP/s).  Durations are HIP events inside the timed region;
+`traffic` / `traffic_ratio` / `mfma_busy_pmc` come from the committed rocprofv3 counter passes (`traffic_source`).
+`cpu_baseline` times the op-for-op torch-CPU restatement of the reference's TF graph (oracle/mvnerf_torch.py, fp32; the reference
+itself cannot run here) on all 4096 rays on the host cores; `parity` checks the GPU result against the NumPy oracle on all 4096
+rays.  `train_cfg4` is the data-parallel training leg (BASELINE.json configs[3]): one 128x128 scene = 16 384 rays per GPU,
+forward with stash + backward + ONE flat all-reduce of the 494 600 gradients + clip + Adam.
 """
 import argparse
 import json
@@ -107,6 +115,8 @@ def main():
     ap.add_argument('--train-steps', type=int, default=5,
                     help='timed train_step calls of the two training legs (cfg2 scene at N=1; cfg4 128x128 scene per GPU with the gradient all-reduce at every N); 0 = skip')
     ap.add_argument('--fused-call', action='store_true', help='time mvnerf_render_fwd (one C call) instead of the op sequence')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='weak: one cfg2 scene per GPU (default, the driver\'s run); strong: the 16 384 rays of ONE 128x128 scene (cfg4) split over the ranks')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -115,7 +125,7 @@ def main():
     import numpy as np
     import torch
     from thesis_clip_nerf_amd import ops
-    from thesis_clip_nerf_amd.distributed import max_over_ranks
+    from thesis_clip_nerf_amd.distributed import max_over_ranks, shard_bounds
     from thesis_clip_nerf_amd.synthetic import make_scene
 
     rank = int(os.environ.get('RANK', 0))
@@ -142,8 +152,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    strong = args.scaling == 'strong'
+    if strong and args.size == 64 and not (args.height or args.width or args.rays):
+        args.size = 128                                           # cfg4's scene: 128 x 128 = 16 384 rays in total
     img_h, img_w = args.height or args.size, args.width or args.size
-    sc = make_scene(seed=rank, batch=1, n_views=args.views, height=img_h, width=img_w, n_rays=args.rays or None)
+    sc = make_scene(seed=0 if strong else rank, batch=1, n_views=args.views, height=img_h, width=img_w, n_rays=args.rays or None)
+    total_rays = sc['rays_o'].shape[1]
+    if strong:                                                    # this rank's contiguous block of the one job's rays
+        lo, hi = shard_bounds(total_rays, rank, world)
+        for k in ('rays_o', 'rays_d', 'u_coarse', 'u_fine'):
+            sc[k] = np.ascontiguousarray(sc[k][:, lo:hi])
     t = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in
          ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'u_coarse', 'u_fine', 'coarse', 'fine']}
     pc, pf = ops.pack_net(t['coarse']), ops.pack_net(t['fine'])
@@ -202,15 +220,16 @@ def main():
     red_dev = dev if backend == 'nccl' else 'cpu'
     elapsed = max_over_ranks(elapsed, red_dev)   # the slowest rank's clock (no-op at world 1)
 
-    rays_per_step = b * r * world
+    rays_per_step = total_rays if strong else b * r * world
     ms_per_step = 1e3 * elapsed / args.steps
     value = rays_per_step * args.steps / elapsed
 
     result = {
         'metric': METRIC, 'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+        'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling,
         'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'f32_gemm': None if bf16 else args.f32_gemm,
-        'config': {'workload': f'cfg2: _call on B=1 scene/GPU, V={args.views} source view {img_h}x{img_w}x(3+256) fp32, '
+        'config': {'workload': (f'cfg4 strong leg: ONE scene of {total_rays} rays split over {world} rank(s) by shard_bounds ({r} rays on rank 0), ' if strong else 'cfg2: ') +
+                               f'_call on B=1 scene/GPU, V={args.views} source view {img_h}x{img_w}x(3+256) fp32, '
                                f'R={r} rays ({"random pixels" if args.rays else "all pixels"} of a {img_h}x{img_w} target), 64 coarse + 128 fine samples/ray, '
                                'two 247300-param ResNet-MLPs (379->128, 3+3 blocks), explicit uniforms',
                    'ray_definition': 'one full _call row: 64 stratified coarse samples + 128 merged fine samples through both MLPs '
@@ -237,10 +256,18 @@ def main():
                  ('<true' if args.views > 1 else '<false') +
                  ((',true>' if use_table else ',false>') if (bf16 or split) else (',false,true>' if use_table else ',false,false>')))
         ref_tflops = fps_ref * b * r * 2 * s / (fine_ms * 1e-3) / 1e12
+        peak_dtype = 'bf16' if (bf16 or split) else 'f32'
         result['roofline'] = {
             'bound': 'mfma', 'kernel': kname + ' (fine pass, S=128)',
-            'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-            'traffic': None, 'flop_per_launch': flops_f, 'avg_launch_ms': fine_ms,
+            'achieved': achieved, 'peak': peak, 'peak_dtype': peak_dtype, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+            # frac_executed: FLOPs issued on the matrix pipe named by peak_dtype / its dense peak (= frac);
+            # frac_algorithmic: SURVEY.md 8d's reference-graph FLOPs (491 264 per sample at V = 1) over the same duration / the same peak
+            'frac_executed': achieved / peak, 'frac_algorithmic': ref_tflops / peak,
+            'peak_note': ('dense bf16 MFMA peak 2.5 PFLOP/s assumes 2.4 GHz; under sustained bf16-MFMA load this chip holds about 1.9-2.0 GHz '
+                          '(in-kernel s_memtime / s_memrealtime, DESIGN.md 4.0), i.e. a matrix pipe that never idles reads about 0.8 here'
+                          if (bf16 or split) else 'fp32 MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md)'),
+            'traffic': None, 'traffic_ratio': None, 'traffic_source': None,
+            'flop_per_launch': flops_f, 'avg_launch_ms': fine_ms,
             'flop_count': f'executed on the matrix pipe: {n_tiles_f} tiles x {mpt} MFMAs x {fpm} FLOP',
             'tiles_per_launch': n_tiles_f, 'mfma_per_tile': mpt,
             'coarse_launch': {'flop_per_launch': flops_c, 'avg_launch_ms': coarse_ms,
@@ -248,8 +275,8 @@ def main():
             'field_kernel_share_of_step': (coarse_ms + fine_ms) / ms_per_step,
             # the literal '64 samples/ray' reading of the metric = the coarse pass alone
             'coarse_only_rays_per_sec': b * r / (coarse_ms * 1e-3),
-            # SURVEY.md 8d's algorithmic figure (491 264 FLOP/sample at V=1) over the same duration; it can exceed 1 because
-            # the PE(dir) rows are hoisted to a per-ray seed and, with the table, the feature rows to per-texel products
+            # SURVEY.md 8d's algorithmic figure (491 264 FLOP/sample at V=1) over the same duration; against the fp32 peak it can
+            # exceed 1 because the PE(dir) rows are hoisted to a per-ray seed and, with the table, the feature rows to per-texel products
             'reference_flop_per_launch': fps_ref * b * r * 2 * s,
             'reference_equiv_tflops': ref_tflops, 'frac_reference_equiv': ref_tflops / peak,
         }
@@ -268,24 +295,31 @@ def main():
                 key = ('field_eval_split_table_fine_hbm_bytes_per_launch' if split else
                        'field_eval_table_fine_hbm_bytes_per_launch' if use_table else 'field_eval_fine_hbm_bytes_per_launch')
                 counters = json.load(open(pmc))
-                result['roofline']['traffic'] = counters.get(key)
+                rl = result['roofline']
+                rl['traffic'] = counters.get(key)
                 if counters.get(key):                  # rocprof counters (profiles/): HBM-side GB/s of this launch, matrix pipe busy
-                    result['roofline']['hbm_gbps_from_pmc_traffic'] = counters[key] / (fine_ms * 1e-3) / 1e9
-                    result['roofline']['mfma_busy_pmc'] = counters.get(key.replace('hbm_bytes_per_launch', 'mfma_busy'))
+                    alg = counters.get('algorithmic_bytes_per_launch')
+                    rl['traffic_algorithmic_bytes'] = alg
+                    rl['traffic_ratio'] = counters[key] / alg if alg else None
+                    rl['traffic_source'] = 'profiles/pmc_traffic.json <- ' + str(counters.get('source_split' if split else 'source_table' if use_table else 'source'))[:160]
+                    rl['traffic_note'] = ('HBM-side bytes (FETCH_SIZE x2 + WRITE_SIZE) exceed the algorithmic bytes because each of the 8 XCD L2s pulls '
+                                          'its own copy of the texel table and the weight stream; at the rate below that is under 1 % of the 8 TB/s HBM peak')
+                    rl['hbm_gbps_from_pmc_traffic'] = counters[key] / (fine_ms * 1e-3) / 1e9
+                    rl['mfma_busy_pmc'] = counters.get(key.replace('hbm_bytes_per_launch', 'mfma_busy'))
                     mops = counters.get(key.replace('hbm_bytes_per_launch', 'mfma_flop_per_launch_pmc'))
                     if mops:
-                        result['roofline']['flop_per_launch_pmc'] = mops
+                        rl['flop_per_launch_pmc'] = mops
             except Exception:
                 pass
 
     if args.train_steps > 0 and not bf16:
-        if world == 1:
+        if world == 1 and not strong:
             result['train_step'] = train_throughput(sc, t, args.views, dev, args.train_steps)
-        leg = train_cfg4(rank, world, dev, backend, args.train_steps, barrier, red_dev)
+        leg = train_cfg4(rank, world, dev, backend, args.train_steps, barrier, red_dev, strong)
         if rank == 0:
             result['train_cfg4'] = leg
     if rank == 0:
-        if world == 1 and args.cpu_baseline == 'on' and (img_h, img_w) == (64, 64) and args.views == 1 and not args.rays:
+        if world == 1 and args.cpu_baseline == 'on' and (img_h, img_w) == (64, 64) and args.views == 1 and not args.rays and not strong:
             result['cpu_baseline'], result['parity'] = cpu_baseline(sc, out)
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -316,20 +350,28 @@ def train_throughput(sc, t, n_views, dev, steps):
             'what': 'train_step: fwd (activations stashed) + bwd of both nets incl. d/d(sample depth) + clip + Adam, fp32'}
 
 
-def train_cfg4(rank, world, dev, backend, steps, barrier, red_dev):
+def train_cfg4(rank, world, dev, backend, steps, barrier, red_dev, strong=False):
     """BASELINE.json configs[3] as restated in SURVEY.md 8d (cfg4): one scene per GPU, 128x128 source view, 16 384 rays (every
     pixel of a 128x128 target), forward with stash + backward + ONE flat all-reduce (mean) of the 494 600 fp32 gradients of both
     MLPs + clip + Adam (model_v0.py:186-197 per rank; the mean over ranks is the gradient of the `world`-scene batch).  Timed
-    like the main leg: barrier + synchronize on both sides, max over ranks; rays/s is the whole job's."""
+    like the main leg: barrier + synchronize on both sides, max over ranks; rays/s is the whole job's.
+    strong: ONE scene's 16 384 rays split over the ranks by shard_bounds (equal blocks for N = 1, 2, 4, 8: the mean over ranks of the
+    per-block mean-squared-error gradients is the whole scene's gradient)."""
     import numpy as np
     import torch
     from thesis_clip_nerf_amd import MVVNeRFRenderer
-    from thesis_clip_nerf_amd.distributed import allreduce_mean_, max_over_ranks
+    from thesis_clip_nerf_amd.distributed import allreduce_mean_, max_over_ranks, shard_bounds
     from thesis_clip_nerf_amd.synthetic import make_scene
-    sc = make_scene(seed=1000 + rank, batch=1, n_views=1, height=128, width=128)
+    sc = make_scene(seed=1000 if strong else 1000 + rank, batch=1, n_views=1, height=128, width=128)
+    total = sc['rays_o'].shape[1]
+    if strong:
+        lo_r, hi_r = shard_bounds(total, rank, world)
+        for k in ('rays_o', 'rays_d', 'u_coarse', 'u_fine'):
+            sc[k] = np.ascontiguousarray(sc[k][:, lo_r:hi_r])
     t = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in
          ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'u_coarse', 'u_fine']}
     r = t['rays_o'].shape[1]
+    job = total if strong else world * r
     m = MVVNeRFRenderer(r, r, n_views=1, near=sc['near'], far=sc['far'], device=dev, seed=0)        # same initial weights on every rank
     m.compile(learning_rate=1e-4, grad_sync=allreduce_mean_ if world > 1 else None)
     inputs = tuple(t[k] for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'])
@@ -348,10 +390,11 @@ def train_cfg4(rank, world, dev, backend, steps, barrier, red_dev):
 
     dt_fwd = timed(lambda: m.infer(inputs, t['features'], u_coarse=t['u_coarse'], u_fine=t['u_fine']), steps, 1)
     dt_train = timed(lambda: m.train_step((inputs, y), **kw), steps, 2)
-    leg = {'workload': 'cfg4: B=1 scene/GPU, V=1 source view 128x128x(3+256) fp32, 16384 rays (all pixels), 64+128 samples/ray',
-           'rays_per_gpu': r, 'steps': steps,
-           'forward_rays_per_sec': world * r / dt_fwd, 'forward_ms_per_step': 1e3 * dt_fwd,
-           'train_rays_per_sec': world * r / dt_train, 'train_ms_per_step': 1e3 * dt_train,
+    leg = {'workload': ('cfg4 strong leg: ONE scene of 16384 rays split over the ranks, ' if strong else 'cfg4: B=1 scene/GPU, ') +
+                       'V=1 source view 128x128x(3+256) fp32, 16384 rays (all pixels), 64+128 samples/ray',
+           'scaling': 'strong' if strong else 'weak', 'rays_per_gpu': r, 'steps': steps,
+           'forward_rays_per_sec': job / dt_fwd, 'forward_ms_per_step': 1e3 * dt_fwd,
+           'train_rays_per_sec': job / dt_train, 'train_ms_per_step': 1e3 * dt_train,
            'what': 'train_step = fwd (stash) + bwd of both nets incl. d/d(sample depth) + flat gradient all-reduce (mean) + clip + Adam, fp32'}
     if world > 1:
         buf = torch.zeros(2 * 247300, dtype=torch.float32, device=dev)
