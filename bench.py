@@ -58,6 +58,10 @@ def mfma_per_tile(v, table, bf16=False, split=False):
     padded; the 60 PE(cam dir) rows are a per-ray seed computed on the vector ALU) + 256 feature rows unless those come from
     the texel table; 12 hidden layers of K = 128; the 128->4 read-out runs on the vector ALU.  One k-step covers K = 2 (fp32
     32x32x2) for each of the 4 output blocks of 32 features."""
+    if split == 16:  # field_eval_split16.hip (default inference kernel): k-steps of K = 32 rows x 8 row blocks x 2 column blocks x 6 products of
+        #              v_mfma_f32_16x16x32_bf16 (16 384 FLOP each); layer 0: 2 k-steps (+ 8 for the feature rows without the texel table);
+        #              6 Dense layers x 4 k-steps per view, 6 x 4 fused; the read-out on the vector ALU
+        return 96 * (v * ((2 if table else 10) + 24) + 24)
     if split:      # field_eval_split.hip: per k-step of 16 rows 4 output blocks x 6 products; PE(dir) in the per-ray seed
         return 24 * (v * ((4 if table else 20) + 48) + 48) + 48
     if bf16:       # field_eval_bf16.hip: K = 16 per MFMA; direct form streams PE(xyz) 64 + PE(dir) 64 + 256 feature rows, the table
@@ -69,7 +73,9 @@ def mfma_per_tile(v, table, bf16=False, split=False):
     return v * (l0 + 6 * hidden) + 6 * hidden
 
 
-def flop_per_mfma(bf16=False):
+def flop_per_mfma(bf16=False, split=False):
+    if split == 16:
+        return 2 * 16 * 16 * 32
     return 2 * 32 * 32 * (16 if bf16 else 2)
 
 
@@ -245,16 +251,19 @@ def main():
         coarse_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         fine_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
         n_tiles_c, n_tiles_f = (b * r * s + 31) // 32, (b * r * 2 * s + 31) // 32
-        mpt = mfma_per_tile(args.views, use_table, bf16, split)
-        fpm = flop_per_mfma(bf16 or split)
+        # which split kernel runs the inference passes: field_eval_split16_kernel unless MVNERF_SPLIT_MFMA=32x32x16 pins the round-2 kernel
+        split_shape = (32 if os.environ.get('MVNERF_SPLIT_MFMA', '').startswith('3') else 16) if split else False
+        mpt = mfma_per_tile(args.views, use_table, bf16, split_shape)
+        fpm = flop_per_mfma(bf16 or bool(split), split_shape)
         flops_c, flops_f = n_tiles_c * mpt * fpm, n_tiles_f * mpt * fpm
         fps_ref = reference_flop_per_sample(args.views)
         # the fine-pass launch is the dominant kernel instance (2/3 of the FLOPs)
         achieved = flops_f / (fine_ms * 1e-3) / 1e12
         peak = 2500.0 if (bf16 or split) else PEAK_FP32_MFMA_TFLOPS   # dense bf16 MFMA peak ~2.5 PFLOP/s
-        kname = (('field_eval_bf16_kernel' if bf16 else 'field_eval_split_kernel' if split else 'field_eval_kernel') +
+        kname = (('field_eval_bf16_kernel' if bf16 else ('field_eval_split16_kernel' if split_shape == 16 else 'field_eval_split_kernel') if split else 'field_eval_kernel') +
                  ('<true' if args.views > 1 else '<false') +
-                 ((',true>' if use_table else ',false>') if (bf16 or split) else (',false,true>' if use_table else ',false,false>')))
+                 ((',true>' if use_table else ',false>') if (bf16 or split_shape == 16) else (',true,false>' if use_table else ',false,false>') if split else
+                  (',false,true>' if use_table else ',false,false>')))
         ref_tflops = fps_ref * b * r * 2 * s / (fine_ms * 1e-3) / 1e12
         peak_dtype = 'bf16' if (bf16 or split) else 'f32'
         result['roofline'] = {
@@ -285,8 +294,9 @@ def main():
             # the matrix-pipe utilisation (executed bf16 FLOPs / 2.5 PFLOP/s); this is the same launch measured in the
             # reference graph's fp32 FLOPs against the fp32 MFMA peak the round-1 kernel was bound by
             result['roofline']['reference_equiv_vs_fp32_mfma_peak'] = ref_tflops / PEAK_FP32_MFMA_TFLOPS
-            result['roofline']['arithmetic'] = ('fp32 operands cut exactly into 3 bf16 pieces, 6 v_mfma_f32_32x32x16_bf16 per product block, '
-                                                'fp32 accumulate (dropped terms <= 2^-24 relative)')
+            result['roofline']['arithmetic'] = ('fp32 operands cut exactly into 3 bf16 pieces, 6 ' +
+                                                ('v_mfma_f32_16x16x32_bf16' if split_shape == 16 else 'v_mfma_f32_32x32x16_bf16') +
+                                                ' per product block, fp32 accumulate (dropped terms <= 2^-24 relative)')
         if use_table:
             result['roofline']['project_texels_ms_per_step'] = float(np.mean([e[4].elapsed_time(e[5]) for e in ev]))
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')

@@ -16,6 +16,7 @@
 // (and / sub / and / sub + byte permutes, in the shadow of the other wave's MFMAs) and issues 24 MFMAs.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 
 #include "mvnerf_kernels.h"
@@ -734,15 +735,27 @@ __global__ __launch_bounds__((kMultiView && MVS_MV_W4) ? 256 : 512, (kMultiView 
 
 }  // namespace
 
+// The packed_split buffer holds two weight streams: this kernel's (32x32x16 MFMA order, kSpChunks KiB) and, behind it, the
+// 16x16x32 kernel's (field_eval_split16.hip), which runs the inference passes.
 hipError_t launch_pack_net_split(const float* net_keras, void* packed_split, hipStream_t st) {
     const int n = kSpChunks * kChunkElems;
     hipLaunchKernelGGL(pack_net_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, net_keras, static_cast<__bf16*>(packed_split));
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_pack_net_split16(net_keras, static_cast<char*>(packed_split) + (size_t)kSpChunks * 1024, st);
 }
 
-size_t packed_net_split_bytes() { return (size_t)kSpChunks * 1024; }
+size_t packed_net_split_bytes() { return (size_t)kSpChunks * 1024 + packed_net_split16_bytes(); }
+
+// MVNERF_SPLIT_MFMA=32x32x16 in the environment keeps every pass on this file's kernel (A/B runs and the tests that pin it)
+static bool split16_enabled() {
+    const char* s = getenv("MVNERF_SPLIT_MFMA");
+    return !(s && s[0] == '3');
+}
 
 hipError_t launch_field_eval_split(const FieldParams& p, const void* packed_split, hipStream_t stream) {
+    if (split16_enabled() && field_eval_split16_supports(p))
+        return launch_field_eval_split16(p, static_cast<const char*>(packed_split) + (size_t)kSpChunks * 1024, stream);
     static std::mutex mtx;
     static bool attr_done[16] = {};
     static int cus[16] = {};

@@ -52,6 +52,12 @@ hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hi
 size_t packed_net_split_bytes();
 hipError_t launch_pack_net_split(const float* net_keras, void* packed_split, hipStream_t st);
 hipError_t launch_field_eval_split(const FieldParams& p, const void* packed_split, hipStream_t stream);
+// field_eval_split16.hip: the same field pass issued as v_mfma_f32_16x16x32_bf16 (inference; its weight stream follows the
+// 32x32x16 kernel's inside the packed_split buffer)
+size_t packed_net_split16_bytes();
+hipError_t launch_pack_net_split16(const float* net_keras, void* packed_split16, hipStream_t st);
+bool field_eval_split16_supports(const FieldParams& p);
+hipError_t launch_field_eval_split16(const FieldParams& p, const void* packed_split16, hipStream_t stream);
 
 hipError_t launch_get_rays(const double* m9, const double* origin3, const float* u, const float* v, int n_rays,
                            int width, int normalize, float* rays_o, float* rays_d, double* rays_d64,
