@@ -347,6 +347,67 @@ int mvnerf_stash_fused_acts(const float* stash, int B, int V, int N, float* acts
 int mvnerf_adam_clip(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1, float beta2,
                      float eps, float clip, const unsigned char* update_mask, mvnerf_stream_t stream);
 
+/* ---- the whole training step behind one call (MVVNeRFRenderer.train_step, model_v0.py:186-197: GradientTape over call(),
+ * loss = MSE(y, rgb) + MSE(y, fine_rgb) :193, gradients :194, optimize() :195 = nerf_utils.py:8-12) ----
+ * The matching `_bwd` of mvnerf_render_fwd: a host in any language takes a training step with these entry points and
+ * a caller-provided workspace; nothing is allocated, nothing synchronises with the host. */
+typedef struct mvnerf_train_call {
+    /* inputs of _call (model_v0.py:113-119): device pointers, layouts as in mvnerf_render_fwd */
+    const float* rays_o;          /* (B,R,3) */
+    const float* rays_d;          /* (B,R,3) */
+    const float* images;          /* (B,V,H,W,3) in [0,1] */
+    const float* features;        /* (B,V,H,W,256) combined_features */
+    const float* intrinsics;      /* (B,V,4,4) */
+    const float* extrinsics_inv;  /* (B,V,4,4) */
+    const float* u_coarse;        /* (B,R,64) the uniforms of sample_along_ray (nerf_utils.py:57) */
+    const float* u_fine;          /* (B,R,64) the uniforms of sample_pdf (nerf_utils.py:151) */
+    const float* labels;          /* (B,R,3) target colours */
+    int B, V, R, S, H, W;         /* S = 64 */
+    double near_, far_;
+    int q7_mode;                  /* MVNERF_Q7_ZERO | MVNERF_Q7_CLAMP */
+    int stop_fine_z;              /* 1: cut the gradient through the importance samples (the reference leaves it open) */
+    int use_texel_tables;         /* 1: forward (and the position / feature-map gradients) through per-texel layer-0 tables built inside the
+                                   * workspace (mvnerf_project_texels2); pays when R*S >= 2*H*W */
+    /* the two MLPs: Keras-order variables (247300 floats each) and the images the kernels read, all caller-owned */
+    const float* net_coarse;      /* updated in place by mvnerf_apply_gradients / mvnerf_train_step */
+    const float* net_fine;
+    const float* packed_coarse;   /* mvnerf_pack_net */
+    const float* packed_fine;
+    const void* split_coarse;     /* mvnerf_pack_net_split, or both NULL: forward on the fp32 MFMA */
+    const void* split_fine;
+    const float* bwd_streams_coarse;   /* mvnerf_pack_bwd_streams */
+    const float* bwd_streams_fine;
+    /* outputs */
+    float* loss;                  /* 1 float: overwritten */
+    float* grad;                  /* 2 x 247300 floats [coarse | fine], Keras order: overwritten */
+    float* rgb;                   /* (B,R,3) */
+    float* depth;                 /* (B,R) */
+    float* fine_rgb;              /* (B,R,3) */
+    float* fine_depth;            /* (B,R) */
+    float* d_features;            /* optional (B,V,H,W,256): overwritten with dL/d(combined_features) - what flows back to the reference's
+                                   * trainable encoders (train_nerf.py:27-32); NULL = not wanted */
+    void* workspace;              /* 256-byte aligned, >= mvnerf_train_workspace_bytes(...) */
+    size_t workspace_bytes;
+} mvnerf_train_call;
+
+typedef struct mvnerf_adam_state {
+    float* m;                     /* 2 x 247300 first moments  [coarse | fine] */
+    float* v;                     /* 2 x 247300 second moments */
+    float lr_t;                   /* bias-corrected rate lr * sqrt(1 - beta2^t) / (1 - beta1^t) (tf.keras Adam) */
+    float beta1, beta2, eps;      /* Keras defaults 0.9, 0.999, 1e-7 */
+    float clip;                   /* clip-by-value bound of optimize() (nerf_utils.py:9), <= 0: none */
+    const unsigned char* update_mask;   /* optional 2 x 247300 bytes, 0 = variable not in the optimizer's list */
+    int repack;                   /* 1: rebuild packed_* / split_* / bwd_streams_* of the call from the updated variables */
+} mvnerf_adam_state;
+
+size_t mvnerf_train_workspace_bytes(int B, int V, int R, int S, int H, int W, int use_texel_tables, int want_d_features);
+/* Forward with stash + loss + full backward: fills loss, grad, the four rendered outputs (and d_features).  model_v0.py:190-194. */
+int mvnerf_loss_and_grads(const mvnerf_train_call* call, mvnerf_stream_t stream);
+/* optimize() on `grad` (a data-parallel host all-reduces it first): clip-by-value, Adam, optional re-pack.  nerf_utils.py:8-12. */
+int mvnerf_apply_gradients(const mvnerf_train_call* call, const mvnerf_adam_state* adam, mvnerf_stream_t stream);
+/* mvnerf_loss_and_grads followed by mvnerf_apply_gradients: MVVNeRFRenderer.train_step on one device. */
+int mvnerf_train_step(const mvnerf_train_call* call, const mvnerf_adam_state* adam, mvnerf_stream_t stream);
+
 /* Bytes of scratch mvnerf_render_fwd needs for (B,V,R,S). */
 size_t mvnerf_render_workspace_bytes(int B, int V, int R, int S);
 

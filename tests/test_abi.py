@@ -83,6 +83,31 @@ def test_argument_validation_of_table_and_query_entry_points():
     assert lib.mvnerf_field_eval_bf16(one, one, one, one, one, None, one, one, one, one, 1, 1, 4, 64, 8, 8, *b_tail) == -3
 
 
+def test_train_step_entry_points_validate_their_structs():
+    lib = _lib.lib()
+    assert lib.mvnerf_train_workspace_bytes(1, 1, 0, 64, 8, 8, 0, 0) == 0
+    small = lib.mvnerf_train_workspace_bytes(1, 1, 64, 64, 8, 8, 0, 0)
+    assert 0 < small < lib.mvnerf_train_workspace_bytes(1, 1, 64, 64, 8, 8, 1, 0) < lib.mvnerf_train_workspace_bytes(1, 1, 64, 64, 8, 8, 1, 1)
+    c = _lib.TrainCall()
+    assert ctypes.sizeof(c) == 9 * 8 + 6 * 4 + 2 * 8 + 3 * 4 + 4 + 16 * 8 + 8             # the layout include/mvnerf_hip.h declares (LP64)
+    assert lib.mvnerf_loss_and_grads(ctypes.byref(c), None) == -1 and b'null pointer' in lib.mvnerf_last_error()
+    for name, _ in _lib.TrainCall._fields_:
+        if _ is ctypes.c_void_p and name not in ('split_coarse', 'split_fine', 'd_features'):
+            setattr(c, name, 256)
+    c.B, c.V, c.R, c.S, c.H, c.W = 1, 1, 8, 32, 8, 8
+    assert lib.mvnerf_loss_and_grads(ctypes.byref(c), None) == -2 and b'n_samples=64' in lib.mvnerf_last_error()
+    c.S = 64
+    c.workspace = 16
+    assert lib.mvnerf_loss_and_grads(ctypes.byref(c), None) == -3
+    c.workspace, c.workspace_bytes = 256, 1000
+    assert lib.mvnerf_loss_and_grads(ctypes.byref(c), None) == -2 and b'workspace' in lib.mvnerf_last_error()
+    c.split_coarse = 256
+    assert lib.mvnerf_loss_and_grads(ctypes.byref(c), None) == -1 and b'both' in lib.mvnerf_last_error()
+    a = _lib.AdamState()
+    assert lib.mvnerf_apply_gradients(ctypes.byref(c), ctypes.byref(a), None) == -1            # no moments
+    assert lib.mvnerf_train_step(None, None, None) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     import pytest
     monkeypatch.setattr(_lib, '_lib', None)

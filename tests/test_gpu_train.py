@@ -326,3 +326,75 @@ def test_deterministic_weight_gradients_are_bit_identical_from_run_to_run():
     assert torch.equal(ga, g1)
     m.compile(deterministic=True)
     assert ops.set_deterministic(False) is True
+
+
+def test_c_abi_train_step_through_ctypes_only():
+    """mvnerf_loss_and_grads / mvnerf_apply_gradients / mvnerf_train_step called straight through ctypes (no MVVNeRFRenderer): what a
+    non-Python host binds.  torch only owns the device memory.  Gradient against the float64 twin at the bars of
+    test_loss_and_grads_match_torch_oracle, then one whole step against the closed-form Adam update."""
+    import ctypes
+    from thesis_clip_nerf_amd import _lib
+    L = _lib.lib()
+    batch, views, n = 2, 1, 24
+    sc = make_scene(seed=61, batch=batch, n_views=views, height=16, width=16, n_rays=n, bias_scale=0.05)
+    y = np.random.default_rng(2).random((batch, n, 3)).astype(np.float32)
+    loss_ref, gc_ref, gf_ref, outs = T.train_loss_and_grads(sc['coarse'], sc['fine'], y, sc, dtype=torch.float64, stop_fine_z=False)
+    d = {k: dev(sc[k]) for k in ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'u_coarse', 'u_fine', 'coarse', 'fine']}
+    d['y'] = dev(y)
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=DEV)
+    u8 = lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    packed = [f32(L.mvnerf_packed_net_floats()) for _ in range(2)]
+    split = [u8(L.mvnerf_packed_net_split_bytes()) for _ in range(2)]
+    bwd = [f32(15 * 16384) for _ in range(2)]
+    for k, name in enumerate(('coarse', 'fine')):
+        assert L.mvnerf_pack_net(P(d[name]), P(packed[k]), None) == 0
+        assert L.mvnerf_pack_net_split(P(d[name]), P(split[k]), None) == 0
+        assert L.mvnerf_pack_bwd_streams(P(d[name]), P(bwd[k]), None) == 0
+    need = L.mvnerf_train_workspace_bytes(batch, views, n, 64, 16, 16, 1, 0)
+    assert need > 0
+    ws = u8(need)
+    loss, grad = f32(1), f32(2 * 247300)
+    outs_t = [f32(batch, n, 3), f32(batch, n), f32(batch, n, 3), f32(batch, n)]
+    c = _lib.TrainCall()
+    for name, t in (('rays_o', d['rays_o']), ('rays_d', d['rays_d']), ('images', d['images']), ('features', d['features']),
+                    ('intrinsics', d['intrinsics']), ('extrinsics_inv', d['extrinsics_inv']), ('u_coarse', d['u_coarse']), ('u_fine', d['u_fine']),
+                    ('labels', d['y']), ('net_coarse', d['coarse']), ('net_fine', d['fine']), ('packed_coarse', packed[0]), ('packed_fine', packed[1]),
+                    ('split_coarse', split[0]), ('split_fine', split[1]), ('bwd_streams_coarse', bwd[0]), ('bwd_streams_fine', bwd[1]),
+                    ('loss', loss), ('grad', grad), ('rgb', outs_t[0]), ('depth', outs_t[1]), ('fine_rgb', outs_t[2]), ('fine_depth', outs_t[3]),
+                    ('workspace', ws)):
+        setattr(c, name, t.data_ptr())
+    c.B, c.V, c.R, c.S, c.H, c.W = batch, views, n, 64, 16, 16
+    c.near_, c.far_, c.q7_mode, c.stop_fine_z, c.use_texel_tables = sc['near'], sc['far'], 0, 0, 1
+    c.workspace_bytes = need - 1
+    assert L.mvnerf_loss_and_grads(ctypes.byref(c), None) == -2 and b'workspace' in L.mvnerf_last_error()     # too small: refused
+    c.workspace_bytes = need
+    assert L.mvnerf_loss_and_grads(ctypes.byref(c), None) == 0
+    torch.cuda.synchronize()
+    assert abs(float(loss) - loss_ref) < 1e-5
+    for g_, r_ in zip(outs_t, outs):
+        assert np.abs(g_.cpu().numpy() - r_).max() < 1e-4
+    g = grad.cpu().numpy()
+    for name, got, ref, bar in (('coarse', g[:247300], gc_ref, 8e-2), ('fine', g[247300:], gf_ref, 6e-3)):
+        for lo, hi in ((0, 48512), (48512, 48640), (48640, 246784), (246784, 247300)):
+            rel = np.linalg.norm(got[lo:hi] - ref[lo:hi]) / np.linalg.norm(ref[lo:hi])
+            assert rel < bar, (name, lo, hi, rel)
+    # one whole step: mvnerf_train_step = the same gradient, clip-by-value, Keras Adam (first step: m = 0.1 g, v = 0.001 g^2), re-pack
+    m_, v_ = torch.zeros(2 * 247300, device=DEV), torch.zeros(2 * 247300, device=DEV)
+    a = _lib.AdamState()
+    a.m, a.v, a.update_mask = m_.data_ptr(), v_.data_ptr(), None
+    lr, b1, b2, eps, clip = 1e-3, 0.9, 0.999, 1e-7, 1.0
+    a.lr_t, a.beta1, a.beta2, a.eps, a.clip, a.repack = lr * np.sqrt(1 - b2) / (1 - b1), b1, b2, eps, clip, 1
+    w0 = np.concatenate([sc['coarse'], sc['fine']]).astype(np.float64)
+    packed_before = packed[1].clone()
+    assert L.mvnerf_train_step(ctypes.byref(c), ctypes.byref(a), None) == 0
+    torch.cuda.synchronize()
+    gclip = np.clip(grad.cpu().numpy().astype(np.float64), -clip, clip)
+    want = w0 - a.lr_t * (0.1 * gclip) / (np.sqrt(0.001 * gclip * gclip) + eps)
+    got = np.concatenate([d['coarse'].cpu().numpy(), d['fine'].cpu().numpy()])
+    assert np.abs(got - want).max() < 2e-6
+    assert not torch.equal(packed_before, packed[1])                        # the forward image was rebuilt from the new variables
+    fresh = f32(L.mvnerf_packed_net_floats())
+    assert L.mvnerf_pack_net(P(d['fine']), P(fresh), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(fresh, packed[1])

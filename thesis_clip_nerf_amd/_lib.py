@@ -17,6 +17,24 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'mvnerf_hip.h')
 NET_PARAMS = 247300
 Q7_ZERO, Q7_CLAMP = 0, 1
 
+
+class TrainCall(ctypes.Structure):
+    """mvnerf_train_call (include/mvnerf_hip.h): one training problem, field for field."""
+    _fields_ = ([(n, c_void_p) for n in ('rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'u_coarse', 'u_fine', 'labels')] +
+                [(n, c_int) for n in ('B', 'V', 'R', 'S', 'H', 'W')] +
+                [('near_', c_double), ('far_', c_double), ('q7_mode', c_int), ('stop_fine_z', c_int), ('use_texel_tables', c_int)] +
+                [(n, c_void_p) for n in ('net_coarse', 'net_fine', 'packed_coarse', 'packed_fine', 'split_coarse', 'split_fine',
+                                         'bwd_streams_coarse', 'bwd_streams_fine', 'loss', 'grad', 'rgb', 'depth', 'fine_rgb', 'fine_depth',
+                                         'd_features', 'workspace')] +
+                [('workspace_bytes', c_size_t)])
+
+
+class AdamState(ctypes.Structure):
+    """mvnerf_adam_state (include/mvnerf_hip.h)."""
+    _fields_ = [('m', c_void_p), ('v', c_void_p), ('lr_t', c_float), ('beta1', c_float), ('beta2', c_float), ('eps', c_float),
+                ('clip', c_float), ('update_mask', c_void_p), ('repack', c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol include/mvnerf_hip.h declares
 # (tests/test_abi.py cross-checks this table against the header and the built library).
 SIGNATURES = {
@@ -75,6 +93,10 @@ SIGNATURES = {
     'mvnerf_field_backward_table': (c_int, [c_void_p] * 14 + [c_int] * 6 + [c_void_p] * 5),
     'mvnerf_adam_clip': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float,
                                  c_void_p, c_void_p]),
+    'mvnerf_train_workspace_bytes': (c_size_t, [c_int] * 8),
+    'mvnerf_loss_and_grads': (c_int, [ctypes.POINTER(TrainCall), c_void_p]),
+    'mvnerf_apply_gradients': (c_int, [ctypes.POINTER(TrainCall), ctypes.POINTER(AdamState), c_void_p]),
+    'mvnerf_train_step': (c_int, [ctypes.POINTER(TrainCall), ctypes.POINTER(AdamState), c_void_p]),
     'mvnerf_render_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'mvnerf_render_fwd': (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_double, c_double, c_int] + [c_void_p] * 6 +
                           [c_int, c_void_p]),

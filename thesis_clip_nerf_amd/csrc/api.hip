@@ -29,6 +29,20 @@ int hip_status(hipError_t e, const char* what) {
     return fail((int)e, "%s: %s", what, hipGetErrorString(e));
 }
 
+}  // namespace
+
+namespace mvnerf {
+int api_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace mvnerf
+
+namespace {
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 struct Workspace {          // carve-up of the caller's scratch for mvnerf_render_fwd (floats)

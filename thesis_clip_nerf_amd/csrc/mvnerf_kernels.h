@@ -39,6 +39,9 @@ struct FieldParams {
     float* dir_tan;        // workspace (B*V*R,128): tangent of the layer-0 seed
 };
 
+// api.hip: records the message mvnerf_last_error() returns and hands `code` back (shared by the extern "C" translation units)
+int api_fail(int code, const char* fmt, ...);
+
 hipError_t launch_pack_net(const float* net_keras, float* packed, hipStream_t stream);
 hipError_t launch_field_eval(const FieldParams& p, hipStream_t stream);
 hipError_t launch_dir_bias(const FieldParams& p, hipStream_t stream);

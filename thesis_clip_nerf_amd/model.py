@@ -72,6 +72,7 @@ class MVVNeRFRenderer:
         self._workspace = None
         self._tables = None             # (2,B,V,H,W,128) texel tables [coarse | fine] of the last scene, see _call
         self._tables_key = None
+        self._last_call = (None, None)  # the mvnerf_train_call of the last loss_and_grads (and the tensors it points to)
 
     # ---- weights -------------------------------------------------------------------------
     def set_weights(self, coarse_net=None, fine_net=None):
@@ -85,12 +86,14 @@ class MVVNeRFRenderer:
         self._packed = None
         self._packed_bwd = None
         self._tables_key = None
+        self._last_call = (None, None)
 
     def weights_changed(self):
         """Call after updating coarse_net / fine_net in place (e.g. an optimizer step)."""
         self._packed = None
         self._packed_bwd = None
         self._tables_key = None
+        self._last_call = (None, None)
 
     def packed(self):
         if self._packed is None:
@@ -220,60 +223,44 @@ class MVVNeRFRenderer:
         upstream feature encoder (trained in the reference, train_nerf.py:27-32) continues from."""
         if not hasattr(self, '_grad'):
             self.compile()
+        call, keep = self._train_call(inputs, labels, combined_features, u_coarse, u_fine, generator, stop_fine_z, return_d_features)
+        ops.loss_and_grads(call, keep['rays_o'])                 # ONE C call: mvnerf_loss_and_grads (csrc/train_api.hip)
+        self._last_call = (call, keep)
+        if return_d_features:
+            return keep['loss'], self._grad, keep['outputs'], keep['d_features']
+        return keep['loss'], self._grad, keep['outputs']
+
+    def _train_call(self, inputs, labels, combined_features, u_coarse, u_fine, generator, stop_fine_z, return_d_features):
+        """The mvnerf_train_call of one step: device tensors checked and bound, workspace and weight images cached per shape."""
         rays_o, rays_d, images, k4, einv = [self._dev(t) for t in inputs]
         feats = self._dev(combined_features)
         y = self._dev(labels)
         b, r, _ = rays_o.shape
+        v, h, w = images.shape[1:4]
         u_coarse, u_fine = self._uniforms(b, r, u_coarse, u_fine, generator)
+        u_coarse, u_fine = self._dev(u_coarse), self._dev(u_fine)
         pc, pf = self.packed()
-        tb = self._train_bufs
-        if tb.get('key') != (b, images.shape[1], r):
-            tb.clear()
-            tb['key'] = (b, images.shape[1], r)
         if self._packed_bwd is None:
             self._packed_bwd = (ops.pack_bwd_streams(self.coarse_net), ops.pack_bwd_streams(self.fine_net))
-        geo = (images, feats, k4, einv)
-        # forward, keeping the trunk pre-activations
-        tab_c = tab_f = None
-        if ops.texel_table_pays(r, self.n_samples, images.shape[2], images.shape[3]):      # forward value only (section 4.1b)
-            if tb.get('tables') is None or tuple(tb['tables'].shape[1:]) != tuple(feats.shape[:4]) + (128,):
-                tb['tables'] = torch.empty((2,) + tuple(feats.shape[:4]) + (128,), dtype=torch.float32, device=self.device)
-            tab_c, tab_f = ops.project_texels2(feats, pc, pf, out=tb['tables']).unbind(0)
-        sp_c, sp_f = self.packed_split() if self.f32_gemm == 'split_bf16' else (None, None)
-        z = ops.stratified_depths(self._dev(u_coarse), self.near, self.far)
-        rgbs_c, tb['stash_c'] = ops.field_eval_stash(rays_o, rays_d, z, *geo, pc, tb.get('stash_c'), texel_table=tab_c, packed_split=sp_c)
-        rgb, depth, w = ops.composite(z, rgbs_c)
-        z_all, rank = ops.resample(z, w, self._dev(u_fine), self.q7_mode, return_rank=True)
-        rgbs_f, tb['stash_f'] = ops.field_eval_stash(rays_o, rays_d, z_all, *geo, pf, tb.get('stash_f'), texel_table=tab_f, packed_split=sp_f)
-        fine_rgb, fine_depth, _ = ops.composite(z_all, rgbs_f, return_weights=False)
-        # loss and its gradient w.r.t. the two rendered images
-        loss = torch.zeros(1, dtype=torch.float32, device=self.device)
-        d_rgb = ops.mse_grad(rgb, y, loss)
-        d_fine = ops.mse_grad(fine_rgb, y, loss)
-        # backward
-        self._grad.zero_()
-        gc, gf = self._grad[:NET_PARAMS], self._grad[NET_PARAMS:]
-        if stop_fine_z:
-            d_rgbs_f, d_z_all, d_w = ops.composite_bwd(z_all, rgbs_f, d_fine), None, None
-        else:
-            d_rgbs_f, d_z_all = ops.composite_bwd(z_all, rgbs_f, d_fine, return_dz=True)
-        d_feat = torch.zeros_like(feats) if return_d_features else None
-        tgrad = None
-        if return_d_features and tab_f is not None:              # scratch for the feature-map gradient through the texel table
-            if tb.get('texel_grad') is None or tuple(tb['texel_grad'].shape) != tuple(tab_f.shape):
-                tb['texel_grad'] = torch.empty_like(tab_f)
-            tgrad = tb['texel_grad']
-        tb['scratch'] = ops.field_backward(rays_o, rays_d, z_all, *geo, self.fine_net, self._packed_bwd[1], tb['stash_f'],
-                                           rgbs_f, d_rgbs_f, gf, tb.get('scratch'), d_z=d_z_all, d_features=d_feat, texel_table=tab_f,
-                                           texel_grad=tgrad)
-        if not stop_fine_z:
-            d_w = ops.resample_bwd(z, w, self._dev(u_fine), rank, d_z_all, self.q7_mode)
-        d_rgbs_c = ops.composite_bwd(z, rgbs_c, d_rgb, d_weights=d_w)
-        tb['scratch'] = ops.field_backward(rays_o, rays_d, z, *geo, self.coarse_net, self._packed_bwd[0], tb['stash_c'],
-                                           rgbs_c, d_rgbs_c, gc, tb['scratch'], d_features=d_feat, texel_table=tab_c, texel_grad=tgrad)
-        if return_d_features:
-            return loss, self._grad, (rgb, depth, fine_rgb, fine_depth), d_feat
-        return loss, self._grad, (rgb, depth, fine_rgb, fine_depth)
+        split = self.packed_split() if self.f32_gemm == 'split_bf16' else None
+        use_tables = ops.texel_table_pays(r, self.n_samples, h, w)      # layer 0's feature rows per texel (DESIGN.md 4.1b)
+        tb = self._train_bufs
+        key = (b, v, r, h, w, bool(return_d_features))
+        if tb.get('key') != key:
+            tb.clear()
+            tb['key'] = key
+            tb['workspace'] = torch.empty(ops.train_workspace_bytes(b, v, r, self.n_samples, h, w, use_tables, return_d_features),
+                                          dtype=torch.uint8, device=self.device)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        outputs = (torch.empty((b, r, 3), dtype=torch.float32, device=self.device), torch.empty((b, r), dtype=torch.float32, device=self.device),
+                   torch.empty((b, r, 3), dtype=torch.float32, device=self.device), torch.empty((b, r), dtype=torch.float32, device=self.device))
+        d_feat = torch.empty_like(feats) if return_d_features else None
+        keep = dict(rays_o=rays_o, rays_d=rays_d, images=images, feats=feats, k4=k4, einv=einv, u=(u_coarse, u_fine), y=y, loss=loss,
+                    outputs=outputs, d_features=d_feat, packed=(pc, pf), split=split, bwd=self._packed_bwd)
+        call = ops.train_call(rays_o, rays_d, images, feats, k4, einv, u_coarse, u_fine, y, self.near, self.far,
+                              (self.coarse_net, self.fine_net), (pc, pf), split, self._packed_bwd, loss, self._grad, outputs, tb['workspace'],
+                              q7_mode=self.q7_mode, stop_fine_z=stop_fine_z, use_tables=use_tables, d_features=d_feat)
+        return call, keep
 
     def train_step(self, data, combined_features=None, u_coarse=None, u_fine=None, generator=None, stop_fine_z=False):
         """model_v0.py:186-197: one optimisation step on (inputs, labels); returns {'loss': 1-element tensor}."""
@@ -319,11 +306,23 @@ class MVVNeRFRenderer:
         lr = o['lr'](o['step']) if callable(o['lr']) else o['lr']
         o['step'] += 1
         lr_t = lr * np.sqrt(1.0 - o['b2'] ** o['step']) / (1.0 - o['b1'] ** o['step'])
-        for k, net in enumerate((self.coarse_net, self.fine_net)):
-            sl = slice(k * NET_PARAMS, (k + 1) * NET_PARAMS)
-            ops.adam_clip(net, grad[sl], self._adam_m[sl], self._adam_v[sl], lr_t, o['b1'], o['b2'], o['eps'], o['clip'],
-                          self._update_mask[sl])
-        self.weights_changed()
+        if grad.data_ptr() != self._grad.data_ptr():
+            self._grad.copy_(grad)
+        adam = ops.adam_state(self._adam_m, self._adam_v, lr_t, o['b1'], o['b2'], o['eps'], o['clip'], self._update_mask, repack=True)
+        call = getattr(self, '_last_call', (None, None))[0]
+        if call is None:                                     # gradients that did not come from loss_and_grads: only the variables move
+            call = ops._lib.TrainCall()
+            call.net_coarse, call.net_fine, call.grad = self.coarse_net.data_ptr(), self.fine_net.data_ptr(), self._grad.data_ptr()
+            ops.apply_gradients(call, adam, self._grad)
+            self.weights_changed()
+            return
+        # mvnerf_apply_gradients: clip + Adam on both MLPs, then the weight images of the call (packed, split, transposed streams) are
+        # rebuilt in place - they are this model's cached ones, so they stay valid; the derived caches are dropped
+        ops.apply_gradients(call, adam, self._grad)
+        self._packed16 = None
+        self._tables_key = None
+        if not call.split_coarse:
+            self._packed_split = None
 
     # ---- checkpoint (model_v0.py:199-240; per-sub-model files, load() -> False if any is missing) ----
     def _split(self, flat):

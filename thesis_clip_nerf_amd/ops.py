@@ -545,6 +545,90 @@ def field_backward(rays_o, rays_d, z, images, features, intrinsics, extrinsics_i
     return scratch
 
 
+def train_workspace_bytes(b, v, r, s, h, w, use_tables, want_d_features):
+    return int(_lib.lib().mvnerf_train_workspace_bytes(int(b), int(v), int(r), int(s), int(h), int(w), int(bool(use_tables)),
+                                                       int(bool(want_d_features))))
+
+
+def train_call(rays_o, rays_d, images, features, intrinsics, extrinsics_inv, u_coarse, u_fine, labels, near, far, nets, packed, split,
+               bwd_streams, loss, grad, outputs, workspace, q7_mode=Q7_ZERO, stop_fine_z=False, use_tables=False, d_features=None):
+    """Fill a mvnerf_train_call (include/mvnerf_hip.h) from device tensors after checking shapes; the caller keeps the tensors alive.
+    nets / packed / split / bwd_streams: (coarse, fine) pairs (split may be None: fp32-MFMA forward); outputs: (rgb, depth, fine_rgb,
+    fine_depth); grad: (2 x 247300,) [coarse | fine]; workspace: uint8 tensor of train_workspace_bytes(...)."""
+    _chk(rays_o, 'rays_o', shape=(None, None, 3))
+    b, r, _ = rays_o.shape
+    _chk(rays_d, 'rays_d', shape=(b, r, 3))
+    _chk(images, 'images', shape=(b, None, None, None, 3))
+    _, v, h, w, _ = images.shape
+    _chk(features, 'features', shape=(b, v, h, w, 256))
+    _chk(intrinsics, 'intrinsics', shape=(b, v, 4, 4))
+    _chk(extrinsics_inv, 'extrinsics_inv', shape=(b, v, 4, 4))
+    _chk(u_coarse, 'u_coarse', shape=(b, r, None))
+    s = u_coarse.shape[2]
+    _chk(u_fine, 'u_fine', shape=(b, r, s))
+    _chk(labels, 'labels', shape=(b, r, 3))
+    for k in range(2):
+        _chk(nets[k], 'net', shape=(NET_PARAMS,))
+        _chk(packed[k], 'packed', shape=(packed_net_floats(),))
+        _chk(bwd_streams[k], 'bwd_streams', shape=(15 * 16384,))
+        if split is not None:
+            _chk(split[k], 'split', dtype=torch.uint8, shape=(int(_lib.lib().mvnerf_packed_net_split_bytes()),))
+    _chk(loss, 'loss', shape=(1,))
+    _chk(grad, 'grad', shape=(2 * NET_PARAMS,))
+    rgb, depth, fine_rgb, fine_depth = outputs
+    _chk(rgb, 'rgb', shape=(b, r, 3))
+    _chk(depth, 'depth', shape=(b, r))
+    _chk(fine_rgb, 'fine_rgb', shape=(b, r, 3))
+    _chk(fine_depth, 'fine_depth', shape=(b, r))
+    if d_features is not None:
+        _chk(d_features, 'd_features', shape=(b, v, h, w, 256))
+    _chk(workspace, 'workspace', dtype=torch.uint8)
+    c = _lib.TrainCall()
+    for name, t in (('rays_o', rays_o), ('rays_d', rays_d), ('images', images), ('features', features), ('intrinsics', intrinsics),
+                    ('extrinsics_inv', extrinsics_inv), ('u_coarse', u_coarse), ('u_fine', u_fine), ('labels', labels),
+                    ('net_coarse', nets[0]), ('net_fine', nets[1]), ('packed_coarse', packed[0]), ('packed_fine', packed[1]),
+                    ('split_coarse', None if split is None else split[0]), ('split_fine', None if split is None else split[1]),
+                    ('bwd_streams_coarse', bwd_streams[0]), ('bwd_streams_fine', bwd_streams[1]), ('loss', loss), ('grad', grad),
+                    ('rgb', rgb), ('depth', depth), ('fine_rgb', fine_rgb), ('fine_depth', fine_depth), ('d_features', d_features),
+                    ('workspace', workspace)):
+        setattr(c, name, None if t is None else t.data_ptr())
+    c.B, c.V, c.R, c.S, c.H, c.W = b, v, r, s, h, w
+    c.near_, c.far_ = float(near), float(far)
+    c.q7_mode, c.stop_fine_z, c.use_texel_tables = int(q7_mode), int(bool(stop_fine_z)), int(bool(use_tables))
+    c.workspace_bytes = workspace.numel()
+    return c
+
+
+def adam_state(m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, clip=1.0, update_mask=None, repack=True):
+    _chk(m, 'm', shape=(2 * NET_PARAMS,))
+    _chk(v, 'v', shape=(2 * NET_PARAMS,))
+    if update_mask is not None:
+        _chk(update_mask, 'update_mask', dtype=torch.uint8, shape=(2 * NET_PARAMS,))
+    a = _lib.AdamState()
+    a.m, a.v, a.update_mask = m.data_ptr(), v.data_ptr(), None if update_mask is None else update_mask.data_ptr()
+    a.lr_t, a.beta1, a.beta2, a.eps, a.clip = float(lr_t), float(beta1), float(beta2), float(eps), float(clip)
+    a.repack = int(bool(repack))
+    return a
+
+
+def loss_and_grads(call, stream_of):
+    """mvnerf_loss_and_grads: MVVNeRFRenderer.train_step's tape (model_v0.py:190-194) on a filled train_call."""
+    with torch.cuda.device(stream_of.device):
+        _lib.check(_lib.lib().mvnerf_loss_and_grads(ctypes.byref(call), _stream(stream_of)), 'loss_and_grads')
+
+
+def apply_gradients(call, adam, stream_of):
+    """mvnerf_apply_gradients: optimize() (nerf_utils.py:8-12) - clip-by-value, Adam, re-pack."""
+    with torch.cuda.device(stream_of.device):
+        _lib.check(_lib.lib().mvnerf_apply_gradients(ctypes.byref(call), ctypes.byref(adam), _stream(stream_of)), 'apply_gradients')
+
+
+def train_step_c(call, adam, stream_of):
+    """mvnerf_train_step: the two above in one C call."""
+    with torch.cuda.device(stream_of.device):
+        _lib.check(_lib.lib().mvnerf_train_step(ctypes.byref(call), ctypes.byref(adam), _stream(stream_of)), 'train_step')
+
+
 def gemm_nt_ok(m, n, k):
     """Shapes mvnerf_gemm_nt takes."""
     return m > 0 and n > 0 and k > 0 and m % 32 == 0 and n % 64 == 0 and k % 8 == 0
