@@ -123,7 +123,20 @@ def test_keras_layout_importers():
     shapes = [(1, 1, 64, 128)] + [(128,)] * 4 + [(7, 7, 3, 64)] + [(64,)] * 4
     for cin in (64, 128, 128):
         shapes += [(3, 3, cin, 128), (128,), (3, 3, 128, 128), (128,)] + [(128,)] * 4
-    E.load_convolutional_encoder(enc, [rng.standard_normal(s).astype(np.float32) if len(s) > 1 else np.abs(rng.standard_normal(s)).astype(np.float32) for s in shapes])
+    E.load_convolutional_encoder(enc, [rng.standard_normal(s).astype(np.float32) if len(s) > 1 else np.abs(rng.standard_normal(s)).astype(np.float32) for s in shapes],
+                                 order='creation')
+    # the Keras `.weights` order (trainable before non-trainable inside a plain Layer; Block 1 carries the downsample branch): a list
+    # exported in that order loads back onto the same variables, and the two orders really differ
+    w_keras = E.convolutional_encoder_weights(enc, order='keras')
+    assert [tuple(a.shape) for a in w_keras[:5]] == [(7, 7, 3, 64), (64,), (64,), (64,), (64,)]                  # stem first
+    assert tuple(w_keras[11].shape) == (1, 1, 64, 128)                                                           # downsample kernel inside Block 1
+    enc2 = E.ConvolutionalEncoder(256)
+    E.load_convolutional_encoder(enc2, w_keras)                                                                  # default: order='keras'
+    for a, b in zip(enc.state_dict().items(), enc2.state_dict().items()):
+        if 'num_batches_tracked' not in a[0]:
+            assert torch.equal(a[1], b[1]), a[0]
+    with pytest.raises(Exception):
+        E.load_convolutional_encoder(E.ConvolutionalEncoder(256), w_keras, order='creation')                     # wrong order: shape mismatch
     blk = E.TransformerBlock(2, 8, 2)
     E.load_transformer_block(blk, [np.ones(8)] * 4 + [qk, np.zeros((2, 4))] * 3 + [np.zeros((2, 4, 8)), np.zeros(8)] + [np.ones(8), np.zeros(8)] +
                              [np.zeros((8, 16)), np.zeros(16), np.zeros((16, 8)), np.zeros(8)])
@@ -139,3 +152,22 @@ def test_feature_optimizer_schedule_matches_warmup_scheduler():
         opt.step()
         sched.step()
     assert opt.defaults['eps'] == 1e-7
+
+
+def test_keras_adam_is_the_keras_update_not_torch_adam():
+    """p -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps): against the closed form over three steps, and different from
+    torch.optim.Adam where it must be (eps added after the bias correction there)."""
+    g = [np.array([1e-8, 2e-3, -0.5], np.float64), np.array([3e-8, -1e-3, 0.25], np.float64), np.array([-2e-8, 5e-4, 0.1], np.float64)]
+    p = torch.nn.Parameter(torch.tensor([0.1, -0.2, 0.3], dtype=torch.float64))
+    q = torch.nn.Parameter(p.detach().clone())
+    opt, ref_opt = E.KerasAdam([p], lr=1e-2, eps=1e-7), torch.optim.Adam([q], lr=1e-2, eps=1e-7)
+    want, m, v = p.detach().numpy().copy(), np.zeros(3), np.zeros(3)
+    for t, gt in enumerate(g, 1):
+        p.grad, q.grad = torch.from_numpy(gt.copy()), torch.from_numpy(gt.copy())
+        opt.step()
+        ref_opt.step()
+        m, v = 0.9 * m + 0.1 * gt, 0.999 * v + 0.001 * gt * gt
+        want = want - 1e-2 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (np.sqrt(v) + 1e-7)
+        np.testing.assert_allclose(p.detach().numpy(), want, rtol=0, atol=1e-15)
+    assert abs(p[0].item() - q[0].item()) > 1e-4          # tiny gradients: the two epsilons act differently
+    assert abs(p[2].item() - q[2].item()) < 1e-6          # large gradients: the same step

@@ -362,8 +362,8 @@ int mvnerf_finish_view(const float* rgb, const float* depth, long n, float* minm
 namespace {
 long tiles_for(int B, int R, int S) { return ((long)B * R * S + 31) / 32; }
 constexpr int kBwdMaxWGs = 512;      // resident workgroups of the dW kernels (2 per CU)
-static_assert(kBwdMaxWGs <= 512, "kPartialFloats is sized for 512 workgroups");
 constexpr int kFusedBwdWGs = 512;    // fused dX+dW kernel: 2 waves/SIMD by registers -> 2 resident workgroups per CU
+static_assert(kBwdMaxWGs == kFusedBwdWGs, "partial_floats() assumes one workgroup budget for every weight-gradient kernel");
 }  // namespace
 
 size_t mvnerf_stash_bytes(int B, int V, int R, int S) {
@@ -371,13 +371,20 @@ size_t mvnerf_stash_bytes(int B, int V, int R, int S) {
     return (size_t)(7 * V + 7) * tiles_for(B, R, S) * 128 * 32 * sizeof(float);     // 7 per-view + 7 fused slots
 }
 
-// deterministic mode: per-workgroup partials of the largest weight-gradient span (layer 0: 379 x 128 + 128 floats)
-constexpr size_t kPartialFloats = (size_t)512 * (mvnerf::kIn * mvnerf::kHidden + mvnerf::kHidden);   // 512 = kBwdMaxWGs = kFusedBwdWGs
+// Per-workgroup partials of a weight-gradient span, summed in workgroup order by reduce_partials_kernel.  The three users:
+// dw0_split8_kernel (layer 0: 379 x 128 + 128 floats per workgroup, kBwdMaxWGs / 2 = 256 workgroups at most, never more than there are
+// view tiles), dense_bwd_split8_kernel (128 x 128 + 128, kFusedBwdWGs / 2) and the read-out's dw_tile_kernel (516 floats, kBwdMaxWGs).
+static size_t partial_floats(long n_tiles, int V) {
+    const long wg0 = n_tiles * V < kBwdMaxWGs / 2 ? n_tiles * V : kBwdMaxWGs / 2;
+    const long wgr = n_tiles < kBwdMaxWGs ? n_tiles : kBwdMaxWGs;
+    const size_t a = (size_t)wg0 * (mvnerf::kIn * mvnerf::kHidden + mvnerf::kHidden), b = (size_t)wgr * 516;
+    return a > b ? a : b;
+}
 std::atomic<int> g_deterministic{0};
 
 size_t mvnerf_field_backward_scratch_bytes(int B, int V, int R, int S) {
     if (B <= 0 || V <= 0 || R <= 0 || S <= 0) return 0;
-    return ((size_t)tiles_for(B, R, S) * ((size_t)3 * V * 128 + 32) * 32 + kPartialFloats) * sizeof(float);
+    return ((size_t)tiles_for(B, R, S) * ((size_t)3 * V * 128 + 32) * 32 + partial_floats(tiles_for(B, R, S), V)) * sizeof(float);
 }
 
 int mvnerf_set_deterministic(int on) { return g_deterministic.exchange(on ? 1 : 0); }

@@ -52,10 +52,10 @@ hipError_t launch_pack_bwd_streams(const float* net_keras, float* dst, hipStream
 
 
 // ---- where a workgroup's weight-gradient partial goes ------------------------------------------------------------------
-// Default: fp32 atomics straight onto the gradient (fast, but the order in which the <= 512 workgroups arrive is not
-// fixed, so the last bits of the gradient vary from run to run).  Deterministic mode (mvnerf_set_deterministic): every
-// workgroup STORES its partial of the contiguous span [dW | db] at part + blockIdx.x * part_stride, and
-// reduce_partials_kernel adds the partials onto the gradient in workgroup order.
+// Every workgroup STORES its partial of the contiguous span [dW | db] at part + blockIdx.x * part_stride, and
+// reduce_partials_kernel adds the partials onto the gradient in workgroup order: bit-identical gradients from run to run, and since
+// round 2 also faster than fp32 atomics onto the same addresses, so api.hip always passes `part` for the weight gradients (the
+// `store == false` atomic form below is still what the kernels do when a caller hands them no partial buffer).
 __device__ __forceinline__ void grad_out(float* dst, float v, bool store) {
     if (store) *dst = v;
     else atomicAdd(dst, v);

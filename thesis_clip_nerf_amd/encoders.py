@@ -351,23 +351,79 @@ def load_combine_clip_visual(module, weights):
     load_conv(module.conv, kernel)
 
 
-def load_convolutional_encoder(enc, weights):
-    """ConvolutionalEncoder.weights in creation order (layers.py:40-53): downsample conv kernel, downsample BN (gamma, beta,
-    mean, var); stem conv kernel, stem BN (4); then per Block: conv_1 kernel, bias, conv_2 kernel, bias, norm_1 (4).
-    (Keras lists trainable variables before the BN moving statistics inside `weights` of a layer: gamma, beta, mean, var.)"""
+def load_convolutional_encoder(enc, weights, order='keras'):
+    """ConvolutionalEncoder variables (layers.py:36-57) as plain arrays.
+
+    order='keras' (default): the order of Keras' `ConvolutionalEncoder.weights`, i.e. `[w.numpy() for w in enc.weights]`: a
+    container lists the weights of its sub-layers in attribute-creation order, and a plain `Layer` (the reference's `Block`)
+    lists ALL its trainable variables first and its non-trainable ones (the BatchNormalization moving statistics) after them:
+      Sequential: stem conv kernel; stem BN gamma, beta, moving_mean, moving_var;
+      Block 1 (has the downsample branch): conv_1 kernel, bias; conv_2 kernel, bias; norm_1 gamma, beta; downsample conv kernel;
+                                           downsample BN gamma, beta | norm_1 moving_mean, moving_var; downsample BN moving_mean, moving_var;
+      Blocks 2, 3: conv_1 kernel, bias; conv_2 kernel, bias; norm_1 gamma, beta | norm_1 moving_mean, moving_var.
+    order='creation' (round 2's reading): downsample conv kernel, downsample BN (gamma, beta, mean, var); stem conv kernel, stem BN (4);
+    per Block conv_1 kernel, bias, conv_2 kernel, bias, norm_1 (gamma, beta, mean, var).
+    Neither order could be checked against a TensorFlow dump here (no TF, no checkpoint in the reference): PARITY UNPINNED.  Prefer
+    keying by variable name (tf.train.list_variables) when a real checkpoint is at hand; a wrong order fails on a shape mismatch
+    for the stem / downsample variables but NOT between same-shaped Block variables."""
     w = list(weights)
     seq = enc.conv_features
+    blocks = (seq[3], seq[4], seq[5])
     down = seq[3].downsample
-    load_conv(down[0], w.pop(0))
-    load_batchnorm(down[1], *[w.pop(0) for _ in range(4)])
-    load_conv(seq[0], w.pop(0))
-    load_batchnorm(seq[1], *[w.pop(0) for _ in range(4)])
-    for blk in (seq[3], seq[4], seq[5]):
-        load_conv(blk.conv_1, w.pop(0), w.pop(0))
-        load_conv(blk.conv_2, w.pop(0), w.pop(0))
-        load_batchnorm(blk.norm_1, *[w.pop(0) for _ in range(4)])
+    if order == 'creation':
+        load_conv(down[0], w.pop(0))
+        load_batchnorm(down[1], *[w.pop(0) for _ in range(4)])
+        load_conv(seq[0], w.pop(0))
+        load_batchnorm(seq[1], *[w.pop(0) for _ in range(4)])
+        for blk in blocks:
+            load_conv(blk.conv_1, w.pop(0), w.pop(0))
+            load_conv(blk.conv_2, w.pop(0), w.pop(0))
+            load_batchnorm(blk.norm_1, *[w.pop(0) for _ in range(4)])
+    elif order == 'keras':
+        load_conv(seq[0], w.pop(0))
+        load_batchnorm(seq[1], *[w.pop(0) for _ in range(4)])
+        for i, blk in enumerate(blocks):
+            load_conv(blk.conv_1, w.pop(0), w.pop(0))
+            load_conv(blk.conv_2, w.pop(0), w.pop(0))
+            gamma, beta = w.pop(0), w.pop(0)
+            if i == 0:
+                load_conv(down[0], w.pop(0))
+                d_gamma, d_beta = w.pop(0), w.pop(0)
+            mean, var = w.pop(0), w.pop(0)
+            load_batchnorm(blk.norm_1, gamma, beta, mean, var)
+            if i == 0:
+                load_batchnorm(down[1], d_gamma, d_beta, w.pop(0), w.pop(0))
+    else:
+        raise ValueError(f"order: {order!r}, expected 'keras' or 'creation'")
     if w:
         raise ValueError(f'{len(w)} unused variables')
+
+
+def convolutional_encoder_weights(enc, order='keras'):
+    """The inverse of load_convolutional_encoder: this module's variables as Keras-layout arrays in the same order."""
+    k_conv = lambda c: c.weight.detach().permute(2, 3, 1, 0).cpu().numpy()
+    bn4 = lambda b: [b.weight.detach().cpu().numpy(), b.bias.detach().cpu().numpy(), b.running_mean.cpu().numpy(), b.running_var.cpu().numpy()]
+    seq = enc.conv_features
+    blocks = (seq[3], seq[4], seq[5])
+    down = seq[3].downsample
+    out = []
+    if order == 'creation':
+        out += [k_conv(down[0])] + bn4(down[1]) + [k_conv(seq[0])] + bn4(seq[1])
+        for blk in blocks:
+            out += [k_conv(blk.conv_1), blk.conv_1.bias.detach().cpu().numpy(), k_conv(blk.conv_2), blk.conv_2.bias.detach().cpu().numpy()] + bn4(blk.norm_1)
+        return out
+    out += [k_conv(seq[0])] + bn4(seq[1])
+    for i, blk in enumerate(blocks):
+        out += [k_conv(blk.conv_1), blk.conv_1.bias.detach().cpu().numpy(), k_conv(blk.conv_2), blk.conv_2.bias.detach().cpu().numpy()]
+        n = bn4(blk.norm_1)
+        out += n[:2]
+        if i == 0:
+            d = bn4(down[1])
+            out += [k_conv(down[0])] + d[:2]
+        out += n[2:]
+        if i == 0:
+            out += d[2:]
+    return out
 
 
 def load_transformer_block(blk, weights):
@@ -396,10 +452,42 @@ def warmup_lr_lambda(warmup_steps=10000, scale_down_after=450000):
     return factor
 
 
+class KerasAdam(torch.optim.Optimizer):
+    """tf.keras.optimizers.Adam's update (the reference's optimizer_feature, train_nerf.py:24-26), which is NOT torch.optim.Adam's:
+        lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t);   p -= lr_t * m / (sqrt(v) + eps)
+    torch adds eps to sqrt(v_hat) after the bias correction, i.e. an effective epsilon larger by 1 / sqrt(1 - beta2^t) (31x at t = 1).
+    The MLP group of the same train_step (mvnerf_adam_clip) uses the Keras form too."""
+
+    def __init__(self, params, lr=1e-5, betas=(0.9, 0.999), eps=1e-7):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            b1, b2 = group['betas']
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st['step'] = 0
+                    st['m'] = torch.zeros_like(p)
+                    st['v'] = torch.zeros_like(p)
+                st['step'] += 1
+                t = st['step']
+                st['m'].mul_(b1).add_(p.grad, alpha=1.0 - b1)
+                st['v'].mul_(b2).addcmul_(p.grad, p.grad, value=1.0 - b2)
+                lr_t = group['lr'] * (1.0 - b2 ** t) ** 0.5 / (1.0 - b1 ** t)
+                p.addcdiv_(st['m'], st['v'].sqrt().add_(group['eps']), value=-lr_t)
+        return loss
+
+
 def make_encoder_optimizer(producer, target_lr=1e-5, warmup_steps=10000, scale_down_after=450000):
-    """The reference's `optimizer_feature` (train_nerf.py:24-31): Keras Adam (eps 1e-7) on vision_transformer + conv_features with
-    the warm-up schedule.  Returns (optimizer, scheduler); call `scheduler.step()` after every `train_step`."""
-    opt = torch.optim.Adam(producer.trainable_parameters(), lr=target_lr, betas=(0.9, 0.999), eps=1e-7)
+    """The reference's `optimizer_feature` (train_nerf.py:24-31): Keras Adam (eps 1e-7, Keras' update form: KerasAdam above) on
+    vision_transformer + conv_features with the warm-up schedule.  Returns (optimizer, scheduler); call `scheduler.step()` after every
+    `train_step`."""
+    opt = KerasAdam(producer.trainable_parameters(), lr=target_lr, betas=(0.9, 0.999), eps=1e-7)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, warmup_lr_lambda(warmup_steps, scale_down_after))
     return opt, sched
 
@@ -410,5 +498,5 @@ def count_parameters(module):
 
 __all__ = ['FeatureProducer', 'VisualFeatures', 'CombineCLIPVisualV0', 'ConvolutionalEncoder', 'VisionTransformerEncoder',
            'VisionTransformer', 'TransformerBlock', 'SyntheticCLIPStage1', 'flat_net_from_keras', 'keras_from_flat_net',
-           'make_encoder_optimizer', 'warmup_lr_lambda', 'load_conv', 'load_conv_transpose', 'load_dense', 'load_batchnorm', 'load_mha',
+           'make_encoder_optimizer', 'KerasAdam', 'convolutional_encoder_weights', 'warmup_lr_lambda', 'load_conv', 'load_conv_transpose', 'load_dense', 'load_batchnorm', 'load_mha',
            'load_combine_clip_visual', 'load_convolutional_encoder', 'load_transformer_block', 'count_parameters']
