@@ -399,13 +399,21 @@ def train_cfg4(rank, world, dev, backend, steps, barrier, red_dev, strong=False)
         return max_over_ranks((time.perf_counter() - t0) / n, red_dev)
 
     dt_fwd = timed(lambda: m.infer(inputs, t['features'], u_coarse=t['u_coarse'], u_fine=t['u_fine']), steps, 1)
+    # data parallel: the fine half of the flat gradient is all-reduced on a second stream while the coarse net's backward still runs
+    # (distributed.OverlappedGradSync, mvnerf_train_call.fine_grad_event); the single flat collective is timed beside it
+    overlap = None
+    if world > 1:
+        from thesis_clip_nerf_amd.distributed import OverlappedGradSync
+        overlap = OverlappedGradSync(dev)
+        m._grad_sync = overlap
     dt_train = timed(lambda: m.train_step((inputs, y), **kw), steps, 2)
     leg = {'workload': ('cfg4 strong leg: ONE scene of 16384 rays split over the ranks, ' if strong else 'cfg4: B=1 scene/GPU, ') +
                        'V=1 source view 128x128x(3+256) fp32, 16384 rays (all pixels), 64+128 samples/ray',
            'scaling': 'strong' if strong else 'weak', 'rays_per_gpu': r, 'steps': steps,
            'forward_rays_per_sec': job / dt_fwd, 'forward_ms_per_step': 1e3 * dt_fwd,
            'train_rays_per_sec': job / dt_train, 'train_ms_per_step': 1e3 * dt_train,
-           'what': 'train_step = fwd (stash) + bwd of both nets incl. d/d(sample depth) + flat gradient all-reduce (mean) + clip + Adam, fp32'}
+           'what': 'train_step = fwd (stash) + bwd of both nets incl. d/d(sample depth) + gradient all-reduce (mean; fine half overlapped with the '
+                   'coarse backward) + clip + Adam, fp32; one C call each for mvnerf_loss_and_grads and mvnerf_apply_gradients'}
     if world > 1:
         buf = torch.zeros(2 * 247300, dtype=torch.float32, device=dev)
         dt_ar = timed(lambda: allreduce_mean_(buf), 20, 3)
@@ -420,6 +428,15 @@ def train_cfg4(rank, world, dev, backend, steps, barrier, red_dev, strong=False)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         leg['weights_identical_across_ranks'] = bool(torch.equal(lo, hi))
+        # the same step with ONE flat all-reduce behind the whole backward, and with no collective at all (ranks then diverge: last)
+        m._grad_sync = allreduce_mean_
+        dt_flat = timed(lambda: m.train_step((inputs, y), **kw), steps, 1)
+        m._grad_sync = None
+        dt_none = timed(lambda: m.train_step((inputs, y), **kw), steps, 1)
+        leg['grad_sync'] = {'overlapped_ms_per_step': 1e3 * dt_train, 'flat_ms_per_step': 1e3 * dt_flat, 'no_collective_ms_per_step': 1e3 * dt_none,
+                            'exposed_ms_overlapped': 1e3 * (dt_train - dt_none), 'exposed_ms_flat': 1e3 * (dt_flat - dt_none),
+                            'note': 'exposed = step time minus the step without any collective; overlapped: fine half (0.99 MB) reduced on a second '
+                                    'stream behind mvnerf_train_call.fine_grad_event while the coarse backward runs, coarse half after it'}
     return leg
 
 

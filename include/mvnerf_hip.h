@@ -388,6 +388,9 @@ typedef struct mvnerf_train_call {
                                    * trainable encoders (train_nerf.py:27-32); NULL = not wanted */
     void* workspace;              /* 256-byte aligned, >= mvnerf_train_workspace_bytes(...) */
     size_t workspace_bytes;
+    void* fine_grad_event;        /* optional hipEvent_t (NULL = none): recorded on the stream as soon as the FINE net's half of `grad` is
+                                   * final, i.e. before the coarse net's backward is launched - a data-parallel host starts that half's
+                                   * all-reduce on a second stream behind this event and overlaps it with the coarse backward */
 } mvnerf_train_call;
 
 typedef struct mvnerf_adam_state {

@@ -41,6 +41,13 @@ def main(out_dir):
         step_loss = m.train_step((inputs, y[mine]), combined_features=sc['features'][mine], **kw)['loss']
         res = {'loss': loss.cpu(), 'local_grad': local_grad.cpu(), 'synced_grad': synced.cpu(), 'step_loss': step_loss.cpu(),
                'coarse_net': m.coarse_net.cpu(), 'fine_net': m.fine_net.cpu()}
+        # the same step with the fine half of the gradient all-reduced on a second stream while the coarse backward runs
+        # (distributed.OverlappedGradSync + mvnerf_train_call.fine_grad_event): the same sums, so the same weights bit for bit
+        m2 = MVVNeRFRenderer(64, 64, n_views=2, batch_size=1, near=sc['near'], far=sc['far'], device=dev)
+        m2.set_weights(sc['coarse'], sc['fine'])
+        m2.compile(learning_rate=1e-3, grad_sync=D.OverlappedGradSync(dev))
+        m2.train_step((inputs, y[mine]), combined_features=sc['features'][mine], **kw)
+        res['coarse_net_overlap'], res['fine_net_overlap'] = m2.coarse_net.cpu(), m2.fine_net.cpu()
 
         # inference: one frame's rays sharded over the ranks, every rank renders its block through the real `_call`
         fr = make_scene(batch=1, **FRAME)

@@ -89,10 +89,10 @@ def test_train_step_entry_points_validate_their_structs():
     small = lib.mvnerf_train_workspace_bytes(1, 1, 64, 64, 8, 8, 0, 0)
     assert 0 < small < lib.mvnerf_train_workspace_bytes(1, 1, 64, 64, 8, 8, 1, 0) < lib.mvnerf_train_workspace_bytes(1, 1, 64, 64, 8, 8, 1, 1)
     c = _lib.TrainCall()
-    assert ctypes.sizeof(c) == 9 * 8 + 6 * 4 + 2 * 8 + 3 * 4 + 4 + 16 * 8 + 8             # the layout include/mvnerf_hip.h declares (LP64)
+    assert ctypes.sizeof(c) == 9 * 8 + 6 * 4 + 2 * 8 + 3 * 4 + 4 + 16 * 8 + 8 + 8         # the layout include/mvnerf_hip.h declares (LP64)
     assert lib.mvnerf_loss_and_grads(ctypes.byref(c), None) == -1 and b'null pointer' in lib.mvnerf_last_error()
     for name, _ in _lib.TrainCall._fields_:
-        if _ is ctypes.c_void_p and name not in ('split_coarse', 'split_fine', 'd_features'):
+        if _ is ctypes.c_void_p and name not in ('split_coarse', 'split_fine', 'd_features', 'fine_grad_event'):
             setattr(c, name, 256)
     c.B, c.V, c.R, c.S, c.H, c.W = 1, 1, 8, 32, 8, 8
     assert lib.mvnerf_loss_and_grads(ctypes.byref(c), None) == -2 and b'n_samples=64' in lib.mvnerf_last_error()

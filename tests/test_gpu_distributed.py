@@ -63,6 +63,11 @@ def test_data_parallel_step_leaves_identical_weights(ranks):
     from tests.dist_gpu_worker import SCENE
     for k in ('coarse_net', 'fine_net'):
         assert torch.equal(ranks[0][k], ranks[1][k]), k
+        # the overlapped all-reduce (two halves on two streams) applies the same averaged gradient
+        assert torch.equal(ranks[0][k + '_overlap'], ranks[1][k + '_overlap']), k
+        # ... which a second model recomputed: for V = 2 the sample-position gradient accumulates with fp32 atomics, so the two runs agree
+        # to rounding, not bit for bit (Adam's first step is ~lr = 1e-3 per weight)
+        assert (ranks[0][k + '_overlap'] - ranks[0][k]).abs().max().item() < 5e-5, k
     # a single-process optimizer step on the mean of the two gradients lands on the same weights.  (train_step recomputed the
     # gradient: the backward accumulates with fp32 atomics, so it equals `synced_grad` only to rounding - hence a tolerance
     # here, while the two ranks above must agree bit for bit because they apply the SAME all-reduced buffer.)
@@ -107,3 +112,21 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0 and d['metric'].startswith('rendered rays/sec')
     assert d['train_cfg4']['weights_identical_across_ranks'] is True and d['train_cfg4']['allreduce_ms'] > 0
     assert 'cpu_baseline' not in d                                     # rank 0 at N = 1 only
+    gs = d['train_cfg4']['grad_sync']
+    assert gs['overlapped_ms_per_step'] > 0 and gs['flat_ms_per_step'] > 0 and gs['no_collective_ms_per_step'] > 0
+
+
+def test_bench_strong_scaling_leg(tmp_path):
+    """`bench.py --gpus 2 --scaling strong`: ONE 128x128 scene's 16 384 rays split over the ranks by shard_bounds (SURVEY.md 8d cfg4,
+    strong leg), rehearsed on one GPU through gloo."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(MVNERF_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--scaling', 'strong', '--steps', '2', '--warmup', '1',
+                           '--train-steps', '1'], env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    d = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{')][0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['config']['rays_per_gpu'] == 8192
+    assert abs(d['value'] * d['ms_per_step'] * 1e-3 - 16384) < 1.0            # value = the whole job's 16 384 rays / step time
+    assert d['train_cfg4']['scaling'] == 'strong' and d['train_cfg4']['rays_per_gpu'] == 8192
+    assert d['train_cfg4']['weights_identical_across_ranks'] is True

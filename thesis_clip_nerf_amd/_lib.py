@@ -26,7 +26,7 @@ class TrainCall(ctypes.Structure):
                 [(n, c_void_p) for n in ('net_coarse', 'net_fine', 'packed_coarse', 'packed_fine', 'split_coarse', 'split_fine',
                                          'bwd_streams_coarse', 'bwd_streams_fine', 'loss', 'grad', 'rgb', 'depth', 'fine_rgb', 'fine_depth',
                                          'd_features', 'workspace')] +
-                [('workspace_bytes', c_size_t)])
+                [('workspace_bytes', c_size_t), ('fine_grad_event', c_void_p)])
 
 
 class AdamState(ctypes.Structure):

@@ -135,6 +135,8 @@ int mvnerf_loss_and_grads(const mvnerf_train_call* c, mvnerf_stream_t stream) {
     MV_RC(mvnerf_field_backward_table(c->rays_o, c->rays_d, w.z_all, c->images, c->features, tab_f, w.texel_grad, c->intrinsics, c->extrinsics_inv,
                                       c->net_fine, c->bwd_streams_fine, w.stash_f, w.rgbs_f, w.d_rgbs_f, B, V, R, 2 * S, H, W, w.bwd_scratch, gf,
                                       c->stop_fine_z ? nullptr : w.d_z_all, c->d_features, stream));
+    if (c->fine_grad_event && hipEventRecord(static_cast<hipEvent_t>(c->fine_grad_event), st) != hipSuccess)
+        return api_fail(1, "mvnerf_loss_and_grads: hipEventRecord(fine_grad_event) failed");
     const float* d_w = nullptr;
     if (!c->stop_fine_z) {                                                  // fine loss -> fine sample depths -> sample_pdf -> coarse weights (F12)
         MV_RC(mvnerf_resample_bwd(w.z, w.weights, c->u_fine, w.rank, w.d_z_all, n_rays, S, c->q7_mode, w.d_w, stream));

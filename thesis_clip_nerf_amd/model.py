@@ -260,6 +260,8 @@ class MVVNeRFRenderer:
         call = ops.train_call(rays_o, rays_d, images, feats, k4, einv, u_coarse, u_fine, y, self.near, self.far,
                               (self.coarse_net, self.fine_net), (pc, pf), split, self._packed_bwd, loss, self._grad, outputs, tb['workspace'],
                               q7_mode=self.q7_mode, stop_fine_z=stop_fine_z, use_tables=use_tables, d_features=d_feat)
+        if hasattr(self._grad_sync, 'event_handle'):         # distributed.OverlappedGradSync: the fine half's all-reduce starts early
+            call.fine_grad_event = self._grad_sync.event_handle()
         return call, keep
 
     def train_step(self, data, combined_features=None, u_coarse=None, u_fine=None, generator=None, stop_fine_z=False):
