@@ -27,8 +27,12 @@ def main():
                 continue
             key, val = m.group(1).strip(), m.group(2)
             if key == 'Function Name':
-                cur = subprocess.run(['c++filt', val], capture_output=True, text=True).stdout.strip()
-                cur = re.sub(r'\(.*$', '', cur).replace('mvnerf::', '').replace('void ', '')
+                # llvm-cxxfilt knows the __bf16 mangling (DF16b); kernels inside an anonymous namespace demangle to
+                # "mvnerf::(anonymous namespace)::name<...>(args)": drop that qualifier BEFORE cutting the argument list at the first "("
+                filt = '/opt/rocm/lib/llvm/bin/llvm-cxxfilt' if os.path.exists('/opt/rocm/lib/llvm/bin/llvm-cxxfilt') else 'c++filt'
+                cur = subprocess.run([filt, val], capture_output=True, text=True).stdout.strip()
+                cur = cur.replace('(anonymous namespace)::', '').replace('mvnerf::', '').replace('void ', '')
+                cur = re.sub(r'\(.*$', '', cur) or val
                 rows[cur] = {}
             elif cur:
                 rows[cur][key] = val

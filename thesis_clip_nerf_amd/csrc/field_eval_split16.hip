@@ -378,7 +378,9 @@ struct SampleGeo {
 };
 
 // kProj: layer 0's feature rows come from the fp32 texel table (project_texels_kernel, field_eval.hip).
-template <bool kMultiView, bool kProj>
+// kAux: the optional outputs (tap indices, pixel coordinates, embedding, the 8 complete_output activations) are compiled in; the plain
+// render variant carries none of the per-sample row indices they need through the tile (fewer spilled registers).
+template <bool kMultiView, bool kProj, bool kAux>
 __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams p, const f32x4* __restrict__ wsplit) {
     constexpr int kW = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s16[];
@@ -422,17 +424,26 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
         long tile = grp * kW + wave;
         const bool tile_ok = tile < p.n_tiles;
         if (!tile_ok) tile = p.n_tiles - 1;                               // idle waves shadow the last tile, no stores
+        // Loop-invariant scalars are re-read here through an empty asm: otherwise the compiler hoists everything derived from them
+        // (float copies of H - 2 and W - 2, the reciprocals of the divisions by S and R, per-lane constants of the positional
+        // encoding, ...) into registers that stay live across the whole tile - next to 2 x 64 accumulators that is ~60 spilled dwords
+        // per lane (a first build: 260 B/lane of scratch, 330 MB of scratch traffic per fine launch by FETCH_SIZE / WRITE_SIZE).
+        // The same for the lane coordinates: every swizzled LDS stage address of the gather (dozens of per-lane constants) is otherwise
+        // computed once in front of the tile loop and kept.
+        int pS = p.S, pR = p.R, pH = p.H, pW = p.W, gl = g, nl = n;
+        asm volatile("" : "+s"(pS), "+s"(pR), "+s"(pH), "+s"(pW));
+        asm volatile("" : "+v"(gl), "+v"(nl));
         SampleGeo sg[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            long gi = tile * 32 + 16 * cb + n;
+            long gi = tile * 32 + 16 * cb + nl;
             sg[cb].valid = tile_ok && gi < p.total;
             if (gi >= p.total) gi = p.total - 1;
             sg[cb].g = gi;
-            const int ray = (int)(gi / p.S);
+            const int ray = (int)((unsigned)gi / (unsigned)pS);              // B*R*S < 2^31 (checked by the C entry points)
             sg[cb].ray = ray;
-            sg[cb].sidx = (int)(gi - (long)ray * p.S);
-            sg[cb].b = ray / p.R;
+            sg[cb].sidx = (int)gi - ray * pS;
+            sg[cb].b = (int)((unsigned)ray / (unsigned)pR);
             const float ox = p.rays_o[3 * ray + 0], oy = p.rays_o[3 * ray + 1], oz = p.rays_o[3 * ray + 2];
             const float dx = p.rays_d[3 * ray + 0], dy = p.rays_d[3 * ray + 1], dz = p.rays_d[3 * ray + 2];
             const float zz = p.z[gi];
@@ -461,14 +472,14 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
                 for (int r = 0; r < 4; ++r) cam[r] = row_dot4(E, r, sg[cb].wx, sg[cb].wy, sg[cb].wz, 1.0f);
                 float pxl, pyl;
                 pixel_from_cam(p.k4 + 16 * bv, cam, &pxl, &pyl);
-                const Taps tp = bilinear_taps(pxl, pyl, p.H, p.W);
-                tl[cb] = (bv * p.H + tp.y0) * p.W + tp.x0;
+                const Taps tp = bilinear_taps(pxl, pyl, pH, pW);
+                tl[cb] = (bv * pH + tp.y0) * pW + tp.x0;
                 ax[cb] = tp.ax;
                 ay[cb] = tp.ay;
-                vrow[cb] = ((long)bv * p.R + (sg[cb].ray - sg[cb].b * p.R)) * p.S + sg[cb].sidx;
-                if (sg[cb].valid && g == 0) {
+                vrow[cb] = ((long)bv * pR + (sg[cb].ray - sg[cb].b * pR)) * pS + sg[cb].sidx;
+                if (kAux && sg[cb].valid && gl == 0) {
                     if (p.tap_idx) {
-                        int4 t4 = make_int4(tl[cb], tl[cb] + 1, tl[cb] + p.W, tl[cb] + p.W + 1);
+                        int4 t4 = make_int4(tl[cb], tl[cb] + 1, tl[cb] + pW, tl[cb] + pW + 1);
                         *reinterpret_cast<int4*>(p.tap_idx + 4 * vrow[cb]) = t4;
                     }
                     if (p.pix) {
@@ -478,22 +489,22 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
                 }
                 // accumulator seed = b0 + W0_dir^T PE(cam dir) of this (view, ray) (dir_bias_kernel, 32x32 accumulator order)
                 {
-                    const f32x4* seed = reinterpret_cast<const f32x4*>(p.dir_bias + 128 * ((long)bv * p.R + (sg[cb].ray - sg[cb].b * p.R)));
+                    const f32x4* seed = reinterpret_cast<const f32x4*>(p.dir_bias + 128 * ((long)bv * pR + (sg[cb].ray - sg[cb].b * pR)));
 #pragma unroll
-                    for (int rb = 0; rb < 8; ++rb) x[rb][cb] = seed[perm_f4(rb, g)];
+                    for (int rb = 0; rb < 8; ++rb) x[rb][cb] = seed[perm_f4(rb, gl)];
                 }
                 // this lane group's 16 of the 64 layer-0 inputs PE(cam xyz) | rgb of the sample (slot order: s16_pe_row).
                 // g < 3: dimension g, octaves 0..7 - accurate sin/cos at octaves 0 and 5, double-angle steps in between
                 // (fl32(x fl32(pi 2^k)) == 2^k fl32(x fl32(pi)) exactly; error x16 at most, as field_eval.hip);
                 // g = 3: octaves 8 and 9 of the three dimensions - accurate at 8, one double-angle step - and the rgb taps.
                 {
-                    const float cd = g == 0 ? cam[0] : (g == 1 ? cam[1] : cam[2]);
-                    const float a0 = (g < 3 ? cd : cam[0]) * 3.14159274101257324f;
-                    const float a1 = (g < 3 ? cd : cam[1]) * 3.14159274101257324f;
+                    const float cd = gl == 0 ? cam[0] : (gl == 1 ? cam[1] : cam[2]);
+                    const float a0 = (gl < 3 ? cd : cam[0]) * 3.14159274101257324f;
+                    const float a1 = (gl < 3 ? cd : cam[1]) * 3.14159274101257324f;
                     const float a2 = cam[2] * 3.14159274101257324f;
                     float s0, c0, s1, c1, s2, c2;
-                    sincos_f32(a0 * (g < 3 ? 1.0f : 256.0f), &s0, &c0);
-                    sincos_f32(a1 * (g < 3 ? 32.0f : 256.0f), &s1, &c1);
+                    sincos_f32(a0 * (gl < 3 ? 1.0f : 256.0f), &s0, &c0);
+                    sincos_f32(a1 * (gl < 3 ? 32.0f : 256.0f), &s1, &c1);
                     sincos_f32(a2 * 256.0f, &s2, &c2);
                     auto dbl = [](float& sk, float& ck) {
                         const float t2 = sk + sk;
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
                         ck = cn;
                     };
                     float va[16], vb[16];
-                    // layout A (g < 3): octaves 0..4 from chain 0, 5..7 from chain 1
+                    // layout A (gl < 3): octaves 0..4 from chain 0, 5..7 from chain 1
                     {
                         float sk = s0, ck = c0;
                         va[0] = sk; va[1] = ck;
@@ -525,13 +536,13 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             const float a = img[c] * 2.0f - 1.0f, bq = img[3 + c] * 2.0f - 1.0f;
-                            const float cq = img[3 * p.W + c] * 2.0f - 1.0f, dq = img[3 * p.W + 3 + c] * 2.0f - 1.0f;
+                            const float cq = img[3 * pW + c] * 2.0f - 1.0f, dq = img[3 * pW + 3 + c] * 2.0f - 1.0f;
                             vb[12 + c] = bilerp(a, bq, cq, dq, tp.ax, tp.ay);
                         }
                         vb[15] = 0.0f;
                     }
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) pe[cb][e] = g < 3 ? va[e] : vb[e];
+                    for (int e = 0; e < 16; ++e) pe[cb][e] = gl < 3 ? va[e] : vb[e];
                 }
             }
 
@@ -555,14 +566,16 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
             }
 
             // ---- layer 0's 256 feature rows through the wave-private fp32 stage ----
+            // (fresh copies of the lane coordinates: the swizzled stage addresses below are computed here, not in front of the tile loop)
+            asm volatile("" : "+v"(gl), "+v"(nl));
             // 16 lanes per sample row (16 B each), 4 rows per load instruction, 4 taps.  kProj: 2 passes over the 128-float table
             // rows [h][nb][16] (pass P = floats h*64 + P*32 + {0..31}), lerped rows ADD into the accumulators; direct: 4 passes
             // of 64 raw channels, the lerped rows are the B operands of 2 k-steps each.
 #pragma unroll
             for (int P = 0; P < (kProj ? 2 : 4); ++P) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const f32x4* tbase = kProj ? reinterpret_cast<const f32x4*>(p.texel_table) + (n >> 3) * 16 + (n & 7) + P * 8
-                                           : reinterpret_cast<const f32x4*>(p.features) + P * 16 + n;
+                const f32x4* tbase = kProj ? reinterpret_cast<const f32x4*>(p.texel_table) + (nl >> 3) * 16 + (nl & 7) + P * 8
+                                           : reinterpret_cast<const f32x4*>(p.features) + P * 16 + nl;
                 const long row_f4 = kProj ? 32 : 64;                       // float4 per texel row
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {                     // staged rows 16 half .. 16 half + 15 = column block `half`
@@ -570,20 +583,20 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
                     float axs[4], ays[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int src = 4 * u + g;                         // sample 16 half + src lives in lane src (any lane group)
+                        const int src = 4 * u + gl;                         // sample 16 half + src lives in lane src (any lane group)
                         const int tls = __shfl(tl[half], src);
                         axs[u] = __shfl(ax[half], src);
                         ays[u] = __shfl(ay[half], src);
                         const f32x4* f = tbase + (long)tls * row_f4;
                         tv[u][0] = f[0];
                         tv[u][1] = f[row_f4];
-                        tv[u][2] = f[(long)p.W * row_f4];
-                        tv[u][3] = f[(long)p.W * row_f4 + row_f4];
+                        tv[u][2] = f[(long)pW * row_f4];
+                        tv[u][3] = f[(long)pW * row_f4 + row_f4];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int src = 16 * half + 4 * u + g;
+                        const int src = 16 * half + 4 * u + gl;
                         f32x4 o;
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
@@ -591,38 +604,38 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
                             const float bot = fmaf(axs[u], tv[u][3][c] - tv[u][2][c], tv[u][2][c]);
                             o[c] = fmaf(ays[u], bot - top, top);
                         }
-                        *reinterpret_cast<f32x4*>(stage + src * kS16StageRowBytes + ((n ^ (src & 15)) << 4)) = o;
+                        *reinterpret_cast<f32x4*>(stage + src * kS16StageRowBytes + ((nl ^ (src & 15)) << 4)) = o;
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (kProj) {
-                    // row blocks 4P .. 4P + 3: chunk 8 (g & 1) + 4 (rbl >> 1) + 2 (rbl & 1) + (g >> 1) of the staged row
+                    // row blocks 4P .. 4P + 3: chunk 8 (gl & 1) + 4 (rbl >> 1) + 2 (rbl & 1) + (gl >> 1) of the staged row
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                         for (int rbl = 0; rbl < 4; ++rbl) {
-                            const int row = 16 * cb + n, chunk = 8 * (g & 1) + 4 * (rbl >> 1) + 2 * (rbl & 1) + (g >> 1);
+                            const int row = 16 * cb + nl, chunk = 8 * (gl & 1) + 4 * (rbl >> 1) + 2 * (rbl & 1) + (gl >> 1);
                             const f32x4 t4 = *reinterpret_cast<const f32x4*>(stage + row * kS16StageRowBytes + ((chunk ^ (row & 15)) << 4));
 #pragma unroll
                             for (int c = 0; c < 4; ++c) x[4 * P + rbl][cb][c] += t4[c];
                         }
                 } else {
-                    // channels 64 P + 32 s + 8 g + {0..7} of this lane's two samples: one k-step per s
+                    // channels 64 P + 32 s + 8 gl + {0..7} of this lane's two samples: one k-step per s
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         B16 bq[2], bqn[2];
                         float nv[2][8];
 #pragma unroll
                         for (int cb = 0; cb < 2; ++cb) {
-                            const int row = 16 * cb + n;
-                            const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * kS16StageRowBytes + (((8 * s + 2 * g) ^ (row & 15)) << 4));
-                            const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * kS16StageRowBytes + (((8 * s + 2 * g + 1) ^ (row & 15)) << 4));
+                            const int row = 16 * cb + nl;
+                            const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * kS16StageRowBytes + (((8 * s + 2 * gl) ^ (row & 15)) << 4));
+                            const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * kS16StageRowBytes + (((8 * s + 2 * gl + 1) ^ (row & 15)) << 4));
                             const float b8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                             cut8<false>(b8, bq[cb]);
 #pragma unroll
                             for (int q = 0; q < 8; ++q) nv[cb][q] = 0.0f;
                         }
-                        kstep16<false, 0, false>(ring, lane, g, bq, nv, bqn, x, x, nullptr);
+                        kstep16<false, 0, false>(ring, lane, gl, bq, nv, bqn, x, x, nullptr);
                         ring16_next(ring);
                     }
                 }
@@ -638,7 +651,7 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
                         for (int rb = 0; rb < 8; ++rb) *reinterpret_cast<f32x4*>(e + 16 * rb) = x[rb][cb];
                     }
             };
-            if (p.acts_view) store_acc16(p.acts_view, vrow);
+            if (kAux && p.acts_view) store_acc16(p.acts_view, vrow);
             // ---- 24 k-steps: the three per-view ResNet blocks.  Only this entry is a layer boundary with exposed vector work (the
             // first operand's cut and the first bias row): every later boundary is prepared in the previous layer's last k-step ----
 #if MVS16_TAIL
@@ -659,7 +672,7 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
                 bias16<true>(bias1 + 128, g, x);
                 dense128_s16_plain(ring, lane, g, hid, x);
 #endif
-                if (p.acts_view) store_acc16(p.acts_view + (bi + 1) * vslot, vrow);
+                if (kAux && p.acts_view) store_acc16(p.acts_view + (bi + 1) * vslot, vrow);
             }
             if (kMultiView) {
 #pragma unroll
@@ -676,17 +689,29 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
                 for (int cb = 0; cb < 2; ++cb) x[rb][cb] = xsum[rb][cb] / nvw;
         }
 
-        const long grow[2] = {sg[0].g, sg[1].g};
+        // the samples' global indices are recomputed here instead of being carried through the whole tile (they would be spilled)
+        long grow[2];
+        bool gvalid[2];
+        {
+            int ne = n;
+            asm volatile("" : "+v"(ne));
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                long gi = tile * 32 + 16 * cb + ne;
+                gvalid[cb] = tile_ok && gi < p.total;
+                grow[cb] = gi >= p.total ? p.total - 1 : gi;
+            }
+        }
         auto store_fused16 = [&](float* base) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
-                if (sg[cb].valid) {
+                if (gvalid[cb]) {
                     float* e = base + 128 * grow[cb] + 4 * g;
 #pragma unroll
                     for (int rb = 0; rb < 8; ++rb) *reinterpret_cast<f32x4*>(e + 16 * rb) = x[rb][cb];
                 }
         };
-        if (p.acts_fused) store_fused16(p.acts_fused);                       // complete_output: the view mean
+        if (kAux && p.acts_fused) store_fused16(p.acts_fused);               // complete_output: the view mean
         // ---- 24 k-steps: fusion blocks ----
 #if MVS16_TAIL
         if (kMultiView) first_operand_s16(x, bop);                           // the view mean is new; V = 1: bop already is the cut of relu(x)
@@ -703,9 +728,9 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
             bias16<true>(bias1 + 128, g, x);
             dense128_s16_plain(ring, lane, g, hid, x);
 #endif
-            if (p.acts_fused) store_fused16(p.acts_fused + (long)(bi - 2) * p.total * 128);
+            if (kAux && p.acts_fused) store_fused16(p.acts_fused + (long)(bi - 2) * p.total * 128);
         }
-        if (p.embedding) store_fused16(p.embedding);
+        if (kAux && p.embedding) store_fused16(p.embedding);
 
         // ---- read-out: Dense 128 -> 4 on relu(x), sigmoid / softplus (layers.py:392-397), on the vector ALU: 32 features per lane
         // x 2 samples x 4 outputs = 256 FMAs, then the sum over the four lane groups (two xor-shuffles)
@@ -736,8 +761,8 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
             // lane group 0 stores column block 0's sample, lane group 1 column block 1's
             const int cbs = g & 1;
             const float o0 = cbs ? o[1][0] : o[0][0], o1 = cbs ? o[1][1] : o[0][1], o2 = cbs ? o[1][2] : o[0][2], o3 = cbs ? o[1][3] : o[0][3];
-            const bool ok = cbs ? sg[1].valid : sg[0].valid;
-            const long gi = cbs ? sg[1].g : sg[0].g;
+            const bool ok = cbs ? gvalid[1] : gvalid[0];
+            const long gi = cbs ? grow[1] : grow[0];
             if (ok && g < 2) {
                 f32x4 out;
                 out[0] = sigmoid_f32(o0);
@@ -782,10 +807,14 @@ hipError_t launch_field_eval_split16(const FieldParams& p, const void* packed_sp
             hipDeviceProp_t prop;
             if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
             cus[dev] = prop.multiProcessorCount;
-            const void* fns[4] = {reinterpret_cast<const void*>(&field_eval_split16_kernel<false, false>),
-                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<false, true>),
-                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<true, false>),
-                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<true, true>)};
+            const void* fns[8] = {reinterpret_cast<const void*>(&field_eval_split16_kernel<false, false, false>),
+                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<false, true, false>),
+                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<true, false, false>),
+                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<true, true, false>),
+                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<false, false, true>),
+                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<false, true, true>),
+                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<true, false, true>),
+                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<true, true, true>)};
             for (const void* fn : fns)
                 if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess) return e;
             attr_done[dev] = true;
@@ -798,13 +827,18 @@ hipError_t launch_field_eval_split16(const FieldParams& p, const void* packed_sp
     const unsigned wgs = (unsigned)(n_groups < resident ? n_groups : resident);
     const f32x4* w = static_cast<const f32x4*>(packed_split16);
     const dim3 grid(wgs), block(512);
-#define MVS16_LAUNCH(MV, PROJ) hipLaunchKernelGGL((field_eval_split16_kernel<MV, PROJ>), grid, block, lds_bytes, stream, p, w)
-    if (mv) {
-        if (p.texel_table) MVS16_LAUNCH(true, true);
-        else MVS16_LAUNCH(true, false);
-    } else {
-        if (p.texel_table) MVS16_LAUNCH(false, true);
-        else MVS16_LAUNCH(false, false);
+#define MVS16_LAUNCH(MV, PROJ, AUX) hipLaunchKernelGGL((field_eval_split16_kernel<MV, PROJ, AUX>), grid, block, lds_bytes, stream, p, w)
+    const bool aux = p.tap_idx || p.pix || p.embedding || p.acts_view || p.acts_fused;
+    const int variant = (mv ? 4 : 0) + (p.texel_table ? 2 : 0) + (aux ? 1 : 0);
+    switch (variant) {
+        case 0: MVS16_LAUNCH(false, false, false); break;
+        case 1: MVS16_LAUNCH(false, false, true); break;
+        case 2: MVS16_LAUNCH(false, true, false); break;
+        case 3: MVS16_LAUNCH(false, true, true); break;
+        case 4: MVS16_LAUNCH(true, false, false); break;
+        case 5: MVS16_LAUNCH(true, false, true); break;
+        case 6: MVS16_LAUNCH(true, true, false); break;
+        default: MVS16_LAUNCH(true, true, true); break;
     }
 #undef MVS16_LAUNCH
     return hipGetLastError();
