@@ -138,6 +138,19 @@ int mvnerf_field_eval_bf16(const float* rays_o, const float* rays_d, const float
                            float* rgbs, int32_t* tap_idx, float* embedding, float* acts_fused, void* workspace,
                            mvnerf_stream_t stream);
 
+/* The two entry points above with the source feature maps STORED as bf16 (B,V,H,W,256) NHWC - BASELINE.json config 5 as SURVEY.md 8d
+ * states it ("feature map + weights bf16"): 512-byte texel rows, what encoders.FeatureProducer(out_dtype=torch.bfloat16) emits.  The
+ * bilinear gather of get_projection_features_mv (nerf_utils.py:277-285) widens the taps to fp32 (exact), lerps in fp32 and rounds once, as
+ * with fp32 maps - so on maps whose fp32 values are bf16-representable the results are bit-identical to the fp32-map entry points;
+ * the projection / gather reads half the bytes.  Source images stay fp32. */
+int mvnerf_project_texels_bf16maps(const void* features_bf16, const void* packed16, const void* packed16_b, int B, int V, int H, int W,
+                                   float* texel_table, float* texel_table_b, mvnerf_stream_t stream);
+int mvnerf_field_eval_bf16maps(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                               const void* features_bf16, const float* texel_table, const float* intrinsics, const float* extrinsics_inv,
+                               const float* packed_net, const void* packed16, int B, int V, int R, int S, int H, int W,
+                               float* rgbs, int32_t* tap_idx, float* embedding, float* acts_fused, void* workspace,
+                               mvnerf_stream_t stream);
+
 /* ---- fp32-grade field pass on the bf16 matrix pipe ("split3"): every fp32 GEMM operand is cut exactly into three
  * bf16 pieces and a product is issued as the six bf16 MFMAs of order >= 2^-16 with fp32 accumulation; the dropped terms
  * are <= 2^-24 relative, one fp32 rounding (csrc/field_eval_split.hip).  Same function, inputs, outputs and 1e-4 bar as

@@ -133,3 +133,53 @@ def test_project_texels_bf16_close_to_fp32_table():
     assert torch.equal(pair[0], t16) and torch.equal(pair[1], t16)
     err = (t16 - t32).abs()
     assert err.mean().item() < 4e-3 * t32.abs().mean().item() and err.max().item() < 3e-2 * t32.abs().max().item()
+
+
+@pytest.mark.parametrize('views', [1, 2])
+def test_bf16_feature_maps_give_the_same_bits_as_fp32_maps_holding_the_same_values(views):
+    """BASELINE.json config 5 as SURVEY.md 8d states it: "feature map + weights bf16".  mvnerf_project_texels_bf16maps /
+    mvnerf_field_eval_bf16maps read (B,V,H,W,256) bfloat16 maps; widening a bf16 tap to fp32 is exact and the lerp / rounding that
+    follows is the fp32-map kernel's, so on fp32 maps holding bf16-representable values both must agree BIT FOR BIT - table,
+    per-sample outputs, tap indices, rendered images - and the restated-arithmetic oracle bar of the fp32-map test carries over."""
+    sc = make_scene(seed=23 + views, batch=2, n_views=views, height=20, width=24, n_rays=96, bias_scale=0.05)
+    d = {k: dev(sc[k]) for k in ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'u_coarse', 'u_fine', 'coarse', 'fine']}
+    maps16 = d['features'].to(torch.bfloat16).contiguous()
+    maps32 = maps16.to(torch.float32).contiguous()
+    assert not torch.equal(maps32, d['features'])                          # the rounding is real
+    pc, pf = ops.pack_net(d['coarse']), ops.pack_net(d['fine'])
+    pc16, pf16 = ops.pack_net_bf16(d['coarse']), ops.pack_net_bf16(d['fine'])
+    t16 = ops.project_texels_bf16(maps16, pc16, packed16_b=pf16)
+    t32 = ops.project_texels_bf16(maps32, pc16, packed16_b=pf16)
+    assert torch.equal(t16, t32)
+    z = ops.stratified_depths(d['u_coarse'], sc['near'], sc['far'])
+    for table16, table32 in ((None, None), (t16[0], t32[0])):
+        geo = lambda f: (d['images'], f, d['intrinsics'], d['extrinsics_inv'])
+        r16, taps16, fused16 = ops.field_eval_bf16(d['rays_o'], d['rays_d'], z, *geo(maps16), pc, pc16, return_taps=True, return_fused_acts=True,
+                                                    texel_table=table16)
+        r32, taps32, fused32 = ops.field_eval_bf16(d['rays_o'], d['rays_d'], z, *geo(maps32), pc, pc16, return_taps=True, return_fused_acts=True,
+                                                    texel_table=table32)
+        assert torch.equal(r16, r32) and torch.equal(taps16, taps32) and torch.equal(fused16, fused32)
+    for tables in ('auto', None):
+        a = ops.render_fwd_bf16(d['rays_o'], d['rays_d'], d['images'], maps16, d['intrinsics'], d['extrinsics_inv'], pc, pf, pc16, pf16,
+                                d['u_coarse'], d['u_fine'], sc['near'], sc['far'], texel_tables=tables)
+        b = ops.render_fwd_bf16(d['rays_o'], d['rays_d'], d['images'], maps32, d['intrinsics'], d['extrinsics_inv'], pc, pf, pc16, pf16,
+                                d['u_coarse'], d['u_fine'], sc['near'], sc['far'], texel_tables=tables)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    # against the oracle restating the bf16 arithmetic, fed the same rounded maps (direct gather: shares every rounding)
+    net = O.unflatten_net(sc['coarse'])
+    rgb_e, sig_e, taps_ref = O.field_eval(net, sc['rays_o'], sc['rays_d'], z.cpu().numpy(), sc['images'], maps32.cpu().numpy(), sc['intrinsics'],
+                                          sc['extrinsics_inv'], return_taps=True, emulate_bf16=True)
+    got, taps = ops.field_eval_bf16(d['rays_o'], d['rays_d'], z, d['images'], maps16, d['intrinsics'], d['extrinsics_inv'], pc, pc16, return_taps=True)
+    np.testing.assert_array_equal(taps.cpu().numpy(), taps_ref)
+    ref = np.concatenate([rgb_e, sig_e[..., None]], -1)
+    assert np.abs(got.cpu().numpy() - ref).mean() < 2e-4
+    # the renderer keeps bf16 maps bf16
+    from thesis_clip_nerf_amd import MVVNeRFRenderer
+    m = MVVNeRFRenderer(96, 96, n_views=views, batch_size=2, near=sc['near'], far=sc['far'], device=DEV, compute_dtype='bf16')
+    m.set_weights(sc['coarse'], sc['fine'])
+    inputs = tuple(sc[k] for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'])
+    o16 = m.infer(inputs, maps16, u_coarse=d['u_coarse'], u_fine=d['u_fine'])
+    o32 = m.infer(inputs, maps32, u_coarse=d['u_coarse'], u_fine=d['u_fine'])
+    for x, y in zip(o16, o32):
+        assert torch.equal(x, y)

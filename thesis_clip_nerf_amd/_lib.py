@@ -59,6 +59,8 @@ SIGNATURES = {
     'mvnerf_project_texels_bf16': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 3),
     'mvnerf_pack_net_bf16': (c_int, [c_void_p, c_void_p, c_void_p]),
     'mvnerf_field_eval_bf16': (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_void_p] * 6),
+    'mvnerf_field_eval_bf16maps': (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_void_p] * 6),
+    'mvnerf_project_texels_bf16maps': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 3),
     'mvnerf_packed_net_split_bytes': (c_size_t, []),
     'mvnerf_pack_net_split': (c_int, [c_void_p, c_void_p, c_void_p]),
     'mvnerf_field_eval_split': (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_void_p] * 8),

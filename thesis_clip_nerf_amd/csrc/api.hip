@@ -196,22 +196,24 @@ int mvnerf_project_texels_bf16(const float* features, const void* packed16, cons
                       "mvnerf_project_texels_bf16");
 }
 
-int mvnerf_field_eval_bf16(const float* rays_o, const float* rays_d, const float* z, const float* images,
+}  // extern "C"
+
+static int field_eval_bf16_impl(const char* who, bool maps_bf16, const float* rays_o, const float* rays_d, const float* z, const float* images,
                            const float* features, const float* texel_table, const float* intrinsics, const float* extrinsics_inv,
                            const float* packed_net, const void* packed16, int B, int V, int R, int S, int H, int W,
                            float* rgbs, int32_t* tap_idx, float* embedding, float* acts_fused, void* workspace,
                            mvnerf_stream_t stream) {
-    if (acts_fused && !aligned16(acts_fused)) return fail(MVNERF_E_ALIGN, "mvnerf_field_eval_bf16: acts_fused must be 16-byte aligned");
-    if (texel_table && !aligned16(texel_table)) return fail(MVNERF_E_ALIGN, "mvnerf_field_eval_bf16: texel_table must be 16-byte aligned");
+    if (acts_fused && !aligned16(acts_fused)) return fail(MVNERF_E_ALIGN, "%s: acts_fused must be 16-byte aligned", who);
+    if (texel_table && !aligned16(texel_table)) return fail(MVNERF_E_ALIGN, "%s: texel_table must be 16-byte aligned", who);
     if (!rays_o || !rays_d || !z || !images || !features || !intrinsics || !extrinsics_inv || !packed_net || !packed16 || !rgbs || !workspace)
-        return fail(MVNERF_E_ARG, "mvnerf_field_eval_bf16: null pointer");
-    if (B <= 0 || V <= 0 || R <= 0 || S <= 0) return fail(MVNERF_E_ARG, "mvnerf_field_eval_bf16: B=%d V=%d R=%d S=%d", B, V, R, S);
-    if (H < 2 || W < 2) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_bf16: source image %dx%d, need H,W >= 2", H, W);
+        return fail(MVNERF_E_ARG, "%s: null pointer", who);
+    if (B <= 0 || V <= 0 || R <= 0 || S <= 0) return fail(MVNERF_E_ARG, "%s: B=%d V=%d R=%d S=%d", who, B, V, R, S);
+    if (H < 2 || W < 2) return fail(MVNERF_E_SHAPE, "%s: source image %dx%d, need H,W >= 2", who, H, W);
     const long total = (long)B * R * S;
-    if (total >= (1L << 31) || (long)B * V * H * W >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_field_eval_bf16: sizes too large for int32 indices");
+    if (total >= (1L << 31) || (long)B * V * H * W >= (1L << 31)) return fail(MVNERF_E_SHAPE, "%s: sizes too large for int32 indices", who);
     if (!aligned16(features) || !aligned16(packed_net) || !aligned16(packed16) || !aligned16(rgbs) || (tap_idx && !aligned16(tap_idx)) ||
         (embedding && !aligned16(embedding)) || !aligned16(workspace))
-        return fail(MVNERF_E_ALIGN, "mvnerf_field_eval_bf16: features, packed nets, rgbs, tap_idx, embedding, workspace must be 16-byte aligned");
+        return fail(MVNERF_E_ALIGN, "%s: features, packed nets, rgbs, tap_idx, embedding, workspace must be 16-byte aligned", who);
     mvnerf::FieldParams p = {};
     p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.images = images; p.features = features;
     p.k4 = intrinsics; p.einv = extrinsics_inv; p.net = packed_net; p.rgbs = rgbs; p.tap_idx = tap_idx; p.embedding = embedding;
@@ -221,7 +223,44 @@ int mvnerf_field_eval_bf16(const float* rays_o, const float* rays_d, const float
     p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W;
     p.total = total;
     p.n_tiles = (total + 31) / 32;
-    return hip_status(mvnerf::launch_field_eval_bf16(p, packed16, static_cast<hipStream_t>(stream)), "mvnerf_field_eval_bf16");
+    return hip_status(mvnerf::launch_field_eval_bf16(p, packed16, static_cast<hipStream_t>(stream), maps_bf16), who);
+}
+
+extern "C" {
+
+int mvnerf_project_texels_bf16maps(const void* features_bf16, const void* packed16, const void* packed16_b, int B, int V, int H, int W,
+                                   float* texel_table, float* texel_table_b, mvnerf_stream_t stream) {
+    if (!features_bf16 || !packed16 || !texel_table) return fail(MVNERF_E_ARG, "mvnerf_project_texels_bf16maps: null pointer");
+    if ((packed16_b == nullptr) != (texel_table_b == nullptr))
+        return fail(MVNERF_E_ARG, "mvnerf_project_texels_bf16maps: the second net and the second table go together");
+    if ((packed16_b && !aligned16(packed16_b)) || (texel_table_b && !aligned16(texel_table_b)))
+        return fail(MVNERF_E_ALIGN, "mvnerf_project_texels_bf16maps: packed16_b, texel_table_b must be 16-byte aligned");
+    if (B <= 0 || V <= 0 || H < 2 || W < 2) return fail(MVNERF_E_ARG, "mvnerf_project_texels_bf16maps: B=%d V=%d H=%d W=%d", B, V, H, W);
+    if ((long)B * V * H * W >= (1L << 31)) return fail(MVNERF_E_SHAPE, "mvnerf_project_texels_bf16maps: B*V*H*W too large for int32 indices");
+    if (!aligned16(features_bf16) || !aligned16(packed16) || !aligned16(texel_table))
+        return fail(MVNERF_E_ALIGN, "mvnerf_project_texels_bf16maps: features_bf16, packed16, texel_table must be 16-byte aligned");
+    return hip_status(mvnerf::launch_project_texels_bf16maps(features_bf16, packed16, packed16_b, (long)B * V * H * W, texel_table, texel_table_b,
+                                                             static_cast<hipStream_t>(stream)),
+                      "mvnerf_project_texels_bf16maps");
+}
+
+int mvnerf_field_eval_bf16(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                           const float* features, const float* texel_table, const float* intrinsics, const float* extrinsics_inv,
+                           const float* packed_net, const void* packed16, int B, int V, int R, int S, int H, int W,
+                           float* rgbs, int32_t* tap_idx, float* embedding, float* acts_fused, void* workspace,
+                           mvnerf_stream_t stream) {
+    return field_eval_bf16_impl("mvnerf_field_eval_bf16", false, rays_o, rays_d, z, images, features, texel_table, intrinsics, extrinsics_inv,
+                                packed_net, packed16, B, V, R, S, H, W, rgbs, tap_idx, embedding, acts_fused, workspace, stream);
+}
+
+int mvnerf_field_eval_bf16maps(const float* rays_o, const float* rays_d, const float* z, const float* images,
+                               const void* features_bf16, const float* texel_table, const float* intrinsics, const float* extrinsics_inv,
+                               const float* packed_net, const void* packed16, int B, int V, int R, int S, int H, int W,
+                               float* rgbs, int32_t* tap_idx, float* embedding, float* acts_fused, void* workspace,
+                               mvnerf_stream_t stream) {
+    return field_eval_bf16_impl("mvnerf_field_eval_bf16maps", true, rays_o, rays_d, z, images, static_cast<const float*>(features_bf16), texel_table,
+                                intrinsics, extrinsics_inv, packed_net, packed16, B, V, R, S, H, W, rgbs, tap_idx, embedding, acts_fused,
+                                workspace, stream);
 }
 
 size_t mvnerf_packed_net_split_bytes(void) { return mvnerf::packed_net_split_bytes(); }

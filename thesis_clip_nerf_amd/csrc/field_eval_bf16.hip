@@ -212,6 +212,9 @@ __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
 // kernel applies to the gathered features, 16x less matrix time than the fp32 projection (which dominates the bf16
 // path on many-texel scenes).  One workgroup per 32 texels: the rows are staged in LDS as bf16 (coalesced fp32 loads,
 // XOR-swizzled 16-byte chunks), wave nb runs the 16 feature k-steps of output block nb on two alternating accumulators.
+// kF16: the feature maps are stored as bf16 (NHWC, 512-byte texel rows - what encoders.FeatureProducer(out_dtype=bfloat16) emits): the rows
+// go to LDS as they are (16-byte chunks of 8 channels), half the HBM bytes of the pass that bounds the bf16 path on many-texel scenes.
+template <bool kF16>
 __global__ __launch_bounds__(512) void project_texels_bf16_kernel(const float* __restrict__ features, const f32x4* __restrict__ w16a,
                                                                   const f32x4* __restrict__ w16b, long n_texels,
                                                                   float* __restrict__ table0, float* __restrict__ table1) {
@@ -225,14 +228,24 @@ __global__ __launch_bounds__(512) void project_texels_bf16_kernel(const float* _
     const long t0 = (long)blockIdx.x * 32;
     const f32x4* fsrc = reinterpret_cast<const f32x4*>(features);
     const int nthreads = blockDim.x;
-    for (int m = 0; m < 2048 / nthreads; ++m) {
-        const int idx = tid + nthreads * m;                 // float4 index inside the 32 x 64 block
-        const int row = idx >> 6, c4 = idx & 63;            // channels 4 c4 .. 4 c4 + 3
-        long t = t0 + row;
-        if (t >= n_texels) t = n_texels - 1;
-        const f32x4 v = fsrc[t * 64 + c4];
-        const int chunk = c4 >> 1;                          // 16-byte chunk of 8 channels
-        *reinterpret_cast<bf16x4*>(srow + row * 512 + ((chunk ^ (row & 15)) << 4) + ((c4 & 1) << 3)) = __builtin_convertvector(v, bf16x4);
+    if (kF16) {
+        for (int m = 0; m < 1024 / nthreads; ++m) {
+            const int idx = tid + nthreads * m;             // 16-byte chunk index inside the 32 x 32 block of bf16 rows
+            const int row = idx >> 5, chunk = idx & 31;     // channels 8 chunk .. 8 chunk + 7
+            long t = t0 + row;
+            if (t >= n_texels) t = n_texels - 1;
+            *reinterpret_cast<f32x4*>(srow + row * 512 + ((chunk ^ (row & 15)) << 4)) = fsrc[t * 32 + chunk];
+        }
+    } else {
+        for (int m = 0; m < 2048 / nthreads; ++m) {
+            const int idx = tid + nthreads * m;             // float4 index inside the 32 x 64 block
+            const int row = idx >> 6, c4 = idx & 63;        // channels 4 c4 .. 4 c4 + 3
+            long t = t0 + row;
+            if (t >= n_texels) t = n_texels - 1;
+            const f32x4 v = fsrc[t * 64 + c4];
+            const int chunk = c4 >> 1;                      // 16-byte chunk of 8 channels
+            *reinterpret_cast<bf16x4*>(srow + row * 512 + ((chunk ^ (row & 15)) << 4) + ((c4 & 1) << 3)) = __builtin_convertvector(v, bf16x4);
+        }
     }
     __syncthreads();
     const f32x4* w = w16 + ((long)16 + nb) * 64 + lane;    // chunk (k-step 4 + ks, nb) = 4 (4 + ks) + nb
@@ -264,8 +277,16 @@ __global__ __launch_bounds__(512) void project_texels_bf16_kernel(const float* _
 
 hipError_t launch_project_texels_bf16(const float* features, const void* packed16, const void* packed16b, long n_texels, float* table,
                                       float* table1, hipStream_t stream) {
-    hipLaunchKernelGGL(project_texels_bf16_kernel, dim3((unsigned)((n_texels + 31) / 32)), dim3(packed16b ? 512 : 256), 0, stream,
+    hipLaunchKernelGGL(project_texels_bf16_kernel<false>, dim3((unsigned)((n_texels + 31) / 32)), dim3(packed16b ? 512 : 256), 0, stream,
                        features, static_cast<const f32x4*>(packed16), static_cast<const f32x4*>(packed16b), n_texels, table, table1);
+    return hipGetLastError();
+}
+
+hipError_t launch_project_texels_bf16maps(const void* features_bf16, const void* packed16, const void* packed16b, long n_texels, float* table,
+                                          float* table1, hipStream_t stream) {
+    hipLaunchKernelGGL(project_texels_bf16_kernel<true>, dim3((unsigned)((n_texels + 31) / 32)), dim3(packed16b ? 512 : 256), 0, stream,
+                       static_cast<const float*>(features_bf16), static_cast<const f32x4*>(packed16), static_cast<const f32x4*>(packed16b), n_texels,
+                       table, table1);
     return hipGetLastError();
 }
 
@@ -379,7 +400,9 @@ constexpr int kStage16Row = 256;      // bytes per staged sample row: 128 channe
 // lerp of table rows added to the accumulators replaces the four feature segments (64 MFMAs per tile) and halves the
 // gather.  All gathers run in batches of 4 iterations with their 16 loads issued up front: the 8 waves of the
 // workgroup share the weight ring, hence gather at the same time, and nothing else hides that latency.
-template <bool kMultiView, bool kProj>
+// kF16 (direct gather only): p.features holds bf16 feature maps (512-byte texel rows); the taps are widened to fp32 (exact), lerped
+// in fp32 and rounded once, as with fp32 maps.
+template <bool kMultiView, bool kProj, bool kF16>
 __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_bf16_kernel(FieldParams p, const f32x4* __restrict__ w16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
     constexpr int kRingBytes = kRing * kSegF4 * 16;                       // 40 or 80 KiB
@@ -552,6 +575,16 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_bf16_kernel(Field
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const f32x4* fbase = reinterpret_cast<const f32x4*>(p.features) + hf * 32 + j;
                 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+                using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+                const u32x2* fbase16 = reinterpret_cast<const u32x2*>(p.features) + hf * 32 + j;      // 8 bytes = channels 4j .. 4j + 3 of the half row
+                auto widen = [](u32x2 q) {                                  // four bf16 -> fp32, exact
+                    f32x4 r;
+                    r[0] = __builtin_bit_cast(float, q[0] << 16);
+                    r[1] = __builtin_bit_cast(float, q[0] & 0xffff0000u);
+                    r[2] = __builtin_bit_cast(float, q[1] << 16);
+                    r[3] = __builtin_bit_cast(float, q[1] & 0xffff0000u);
+                    return r;
+                };
 #pragma unroll 1
                 for (int it0 = 0; it0 < (MV16_ABL_GATHER ? 0 : 16); it0 += 4) {
                     f32x4 tv[4][4];
@@ -562,11 +595,19 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_bf16_kernel(Field
                         const int tls = __shfl(tl, src);
                         axs[u] = __shfl(tp.ax, src);
                         ays[u] = __shfl(tp.ay, src);
-                        const f32x4* f = fbase + (long)tls * 64;
-                        tv[u][0] = f[0];
-                        tv[u][1] = f[64];
-                        tv[u][2] = f[(long)p.W * 64];
-                        tv[u][3] = f[(long)p.W * 64 + 64];
+                        if (kF16) {
+                            const u32x2* f = fbase16 + (long)tls * 64;
+                            tv[u][0] = widen(f[0]);
+                            tv[u][1] = widen(f[64]);
+                            tv[u][2] = widen(f[(long)p.W * 64]);
+                            tv[u][3] = widen(f[(long)p.W * 64 + 64]);
+                        } else {
+                            const f32x4* f = fbase + (long)tls * 64;
+                            tv[u][0] = f[0];
+                            tv[u][1] = f[64];
+                            tv[u][2] = f[(long)p.W * 64];
+                            tv[u][3] = f[(long)p.W * 64 + 64];
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -666,7 +707,7 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_bf16_kernel(Field
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // DMA still in flight must land before the LDS is released
 }
 
-hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hipStream_t stream) {
+hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hipStream_t stream, bool maps_bf16) {
     static std::mutex mtx;
     static bool attr_done[16] = {};
     static int cus[16] = {};
@@ -681,10 +722,12 @@ hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hi
             hipDeviceProp_t prop;
             if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
             cus[dev] = prop.multiProcessorCount;
-            const void* fns[4] = {reinterpret_cast<const void*>(&field_eval_bf16_kernel<false, false>),
-                                  reinterpret_cast<const void*>(&field_eval_bf16_kernel<false, true>),
-                                  reinterpret_cast<const void*>(&field_eval_bf16_kernel<true, false>),
-                                  reinterpret_cast<const void*>(&field_eval_bf16_kernel<true, true>)};
+            const void* fns[6] = {reinterpret_cast<const void*>(&field_eval_bf16_kernel<false, false, false>),
+                                  reinterpret_cast<const void*>(&field_eval_bf16_kernel<false, true, false>),
+                                  reinterpret_cast<const void*>(&field_eval_bf16_kernel<true, false, false>),
+                                  reinterpret_cast<const void*>(&field_eval_bf16_kernel<true, true, false>),
+                                  reinterpret_cast<const void*>(&field_eval_bf16_kernel<false, false, true>),
+                                  reinterpret_cast<const void*>(&field_eval_bf16_kernel<true, false, true>)};
             for (const void* fn : fns)
                 if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess) return e;
             attr_done[dev] = true;
@@ -695,13 +738,17 @@ hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hi
     const long resident = (long)cus[dev] * (8 / kWgWaves);                 // persistent: as many workgroups as fit at once
     const unsigned wgs = (unsigned)(n_groups < resident ? n_groups : resident);
     const f32x4* w16 = static_cast<const f32x4*>(packed16);
+#define MV16_GO(MV, PROJ, F16) hipLaunchKernelGGL((field_eval_bf16_kernel<MV, PROJ, F16>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w16)
     if (p.V > 1) {
-        if (p.texel_table) hipLaunchKernelGGL((field_eval_bf16_kernel<true, true>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w16);
-        else hipLaunchKernelGGL((field_eval_bf16_kernel<true, false>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w16);
+        if (p.texel_table) MV16_GO(true, true, false);                     // with the table the feature maps are not read at all
+        else if (maps_bf16) MV16_GO(true, false, true);
+        else MV16_GO(true, false, false);
     } else {
-        if (p.texel_table) hipLaunchKernelGGL((field_eval_bf16_kernel<false, true>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w16);
-        else hipLaunchKernelGGL((field_eval_bf16_kernel<false, false>), dim3(wgs), dim3(64 * kWgWaves), lds_bytes, stream, p, w16);
+        if (p.texel_table) MV16_GO(false, true, false);
+        else if (maps_bf16) MV16_GO(false, false, true);
+        else MV16_GO(false, false, false);
     }
+#undef MV16_GO
     return hipGetLastError();
 }
 

@@ -51,7 +51,9 @@ hipError_t launch_field_jvp(const FieldParams& p, hipStream_t stream);
 hipError_t launch_pack_net_bf16(const float* net_keras, void* packed16, hipStream_t st);
 hipError_t launch_project_texels_bf16(const float* features, const void* packed16, const void* packed16b, long n_texels, float* table,
                                       float* table1, hipStream_t stream);
-hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hipStream_t stream);
+hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hipStream_t stream, bool maps_bf16 = false);   // maps_bf16: p.features holds bf16
+hipError_t launch_project_texels_bf16maps(const void* features_bf16, const void* packed16, const void* packed16b, long n_texels, float* table,
+                                          float* table1, hipStream_t stream);
 size_t packed_net_split_bytes();
 hipError_t launch_pack_net_split(const float* net_keras, void* packed_split, hipStream_t st);
 hipError_t launch_field_eval_split(const FieldParams& p, const void* packed_split, hipStream_t stream);

@@ -139,7 +139,11 @@ class MVVNeRFRenderer:
         cheaper: always rebuilt for a call with R*S >= 2*H*W; with `scene_key` (any hashable naming the feature maps,
         e.g. one frame rendered in chunks) they are built by the first call and re-used while key and weights last."""
         rays_o, rays_d, images, k4, einv = [self._dev(t) for t in inputs]
-        features = self._dev(combined_features)
+        if self.compute_dtype == 'bf16' and isinstance(combined_features, torch.Tensor) and combined_features.dtype == torch.bfloat16:
+            # bf16 feature maps stay bf16 (encoders.FeatureProducer(out_dtype=torch.bfloat16)): the bf16 passes read them as stored
+            features = combined_features.to(self.device).contiguous()
+        else:
+            features = self._dev(combined_features)
         if rays_o.dim() != 3 or rays_o.shape[0] != batch_size or rays_o.shape[1] != n_rays:
             raise ValueError(f'ray_origins: shape {tuple(rays_o.shape)}, expected ({batch_size}, {n_rays}, 3)')
         u_coarse, u_fine = self._uniforms(batch_size, n_rays, u_coarse, u_fine, generator)

@@ -707,8 +707,10 @@ def pack_net_bf16(net_keras):
 
 def project_texels_bf16(features, packed16, out=None, packed16_b=None):
     """mvnerf_project_texels_bf16: the texel table of one net on the bf16 MFMA (fp32 table, same layout as project_texels);
-    with packed16_b both nets' tables (2,B,V,H,W,128) from one read of the feature maps."""
-    _chk(features, 'features', shape=(None, None, None, None, 256))
+    with packed16_b both nets' tables (2,B,V,H,W,128) from one read of the feature maps.
+    features: fp32, or bfloat16 (B,V,H,W,256) -> mvnerf_project_texels_bf16maps (half the bytes of the pass)."""
+    maps16 = isinstance(features, torch.Tensor) and features.dtype == torch.bfloat16
+    _chk(features, 'features', dtype=torch.bfloat16 if maps16 else torch.float32, shape=(None, None, None, None, 256))
     b, v, h, w, _ = features.shape
     nbytes = int(_lib.lib().mvnerf_packed_net_bf16_bytes())
     _chk(packed16, 'packed16', dtype=torch.uint8, shape=(nbytes,))
@@ -721,8 +723,8 @@ def project_texels_bf16(features, packed16, out=None, packed16_b=None):
         _chk(out, 'texel_table', shape=shape)
     t0, t1 = (out, None) if packed16_b is None else (out[0], out[1])
     with torch.cuda.device(features.device):
-        rc = _lib.lib().mvnerf_project_texels_bf16(_p(features), _p(packed16), _p(packed16_b), b, v, h, w, _p(t0), _p(t1),
-                                                   _stream(features))
+        fn = _lib.lib().mvnerf_project_texels_bf16maps if maps16 else _lib.lib().mvnerf_project_texels_bf16
+        rc = fn(_p(features), _p(packed16), _p(packed16_b), b, v, h, w, _p(t0), _p(t1), _stream(features))
     _lib.check(rc, 'project_texels_bf16')
     return out
 
@@ -730,7 +732,9 @@ def project_texels_bf16(features, packed16, out=None, packed16_b=None):
 def field_eval_bf16(rays_o, rays_d, z, images, features, intrinsics, extrinsics_inv, packed_net, packed16, return_taps=False,
                     return_embedding=False, return_fused_acts=False, texel_table=None):
     """mvnerf_field_eval_bf16: as field_eval with the Dense layers on the bf16 MFMA path.
-    return_fused_acts: + (4,B,R,S,128) = view mean and the three fusion blocks (complete_output[4:])."""
+    return_fused_acts: + (4,B,R,S,128) = view mean and the three fusion blocks (complete_output[4:]).
+    features: fp32, or bfloat16 (B,V,H,W,256) -> mvnerf_field_eval_bf16maps (the gather reads bf16 texel rows)."""
+    maps16 = isinstance(features, torch.Tensor) and features.dtype == torch.bfloat16
     _chk(rays_o, 'rays_o', shape=(None, None, 3))
     b, r, _ = rays_o.shape
     _chk(rays_d, 'rays_d', shape=(b, r, 3))
@@ -738,7 +742,7 @@ def field_eval_bf16(rays_o, rays_d, z, images, features, intrinsics, extrinsics_
     s = z.shape[2]
     _chk(images, 'images', shape=(b, None, None, None, 3))
     _, v, h, w, _ = images.shape
-    _chk(features, 'features', shape=(b, v, h, w, 256))
+    _chk(features, 'features', dtype=torch.bfloat16 if maps16 else torch.float32, shape=(b, v, h, w, 256))
     _chk(intrinsics, 'intrinsics', shape=(b, v, 4, 4))
     _chk(extrinsics_inv, 'extrinsics_inv', shape=(b, v, 4, 4))
     _chk(packed_net, 'packed_net', shape=(packed_net_floats(),))
@@ -752,9 +756,9 @@ def field_eval_bf16(rays_o, rays_d, z, images, features, intrinsics, extrinsics_
         _chk(texel_table, 'texel_table', shape=(b, v, h, w, 128))
     ws = torch.empty(int(_lib.lib().mvnerf_field_workspace_bytes(b, v, r)), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        rc = _lib.lib().mvnerf_field_eval_bf16(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(texel_table), _p(intrinsics),
-                                               _p(extrinsics_inv), _p(packed_net), _p(packed16), b, v, r, s, h, w, _p(rgbs),
-                                               _p(taps), _p(emb), _p(fused), _p(ws), _stream(rays_o))
+        fn = _lib.lib().mvnerf_field_eval_bf16maps if maps16 else _lib.lib().mvnerf_field_eval_bf16
+        rc = fn(_p(rays_o), _p(rays_d), _p(z), _p(images), _p(features), _p(texel_table), _p(intrinsics), _p(extrinsics_inv), _p(packed_net),
+                _p(packed16), b, v, r, s, h, w, _p(rgbs), _p(taps), _p(emb), _p(fused), _p(ws), _stream(rays_o))
     _lib.check(rc, 'field_eval_bf16')
     out = (rgbs,) + ((taps,) if return_taps else ()) + ((emb,) if return_embedding else ()) + ((fused,) if return_fused_acts else ())
     return out if len(out) > 1 else rgbs
