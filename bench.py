@@ -302,7 +302,8 @@ def main():
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc) and not bf16 and (use_table or not split) and args.views == 1 and (img_h, img_w, r) == (64, 64, 4096):   # counters were collected on cfg2
             try:
-                key = ('field_eval_split_table_fine_hbm_bytes_per_launch' if split else
+                key = ('field_eval_split16_table_fine_hbm_bytes_per_launch' if split_shape == 16 else
+                       'field_eval_split_table_fine_hbm_bytes_per_launch' if split else
                        'field_eval_table_fine_hbm_bytes_per_launch' if use_table else 'field_eval_fine_hbm_bytes_per_launch')
                 counters = json.load(open(pmc))
                 rl = result['roofline']
@@ -311,9 +312,10 @@ def main():
                     alg = counters.get('algorithmic_bytes_per_launch')
                     rl['traffic_algorithmic_bytes'] = alg
                     rl['traffic_ratio'] = counters[key] / alg if alg else None
-                    rl['traffic_source'] = 'profiles/pmc_traffic.json <- ' + str(counters.get('source_split' if split else 'source_table' if use_table else 'source'))[:160]
+                    rl['traffic_source'] = 'profiles/pmc_traffic.json <- ' + str(counters.get('source_split16' if split_shape == 16 else 'source_split' if split else 'source_table' if use_table else 'source'))[:200]
                     rl['traffic_note'] = ('HBM-side bytes (FETCH_SIZE x2 + WRITE_SIZE) exceed the algorithmic bytes because each of the 8 XCD L2s pulls '
-                                          'its own copy of the texel table and the weight stream; at the rate below that is under 1 % of the 8 TB/s HBM peak')
+                                          'its own copy of the texel table and the weight stream, and because of the kernel\'s remaining register spills '
+                                          '(scratch); at the rate below that is about 1 % of the 8 TB/s HBM peak')
                     rl['hbm_gbps_from_pmc_traffic'] = counters[key] / (fine_ms * 1e-3) / 1e9
                     rl['mfma_busy_pmc'] = counters.get(key.replace('hbm_bytes_per_launch', 'mfma_busy'))
                     mops = counters.get(key.replace('hbm_bytes_per_launch', 'mfma_flop_per_launch_pmc'))
