@@ -30,11 +30,15 @@ def test_train_step_calls_schedule_with_pre_increment_step(monkeypatch):
     r._encoder_optimizer = None
     r._adam_m = r._adam_v = r._update_mask = torch.zeros(2 * M.NET_PARAMS)
     r.coarse_net = r.fine_net = torch.zeros(M.NET_PARAMS)
-    r.loss_and_grads = lambda *a, **k: (torch.zeros(1), torch.zeros(2 * M.NET_PARAMS), None)
+    r._grad = torch.zeros(2 * M.NET_PARAMS)
+    r._last_call = (None, None)
+    r.loss_and_grads = lambda *a, **k: (torch.zeros(1), r._grad, None)
     r.weights_changed = lambda: None
-    monkeypatch.setattr(M.ops, 'adam_clip', lambda net, g, m, v, lr_t, *a: lr_ts.append(lr_t))
+    # the optimizer step is ONE C call (mvnerf_apply_gradients) on a mvnerf_adam_state: record the bias-corrected rate it is given
+    monkeypatch.setattr(M.ops, 'adam_state', lambda m, v, lr_t, *a, **k: lr_ts.append(lr_t) or object())
+    monkeypatch.setattr(M.ops, 'apply_gradients', lambda call, adam, stream_of: None)
     for _ in range(3):
         r.train_step((None, None), combined_features=object())
     assert seen == [0, 1, 2]
     want = [1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) for t in (1, 2, 3)]
-    assert np.allclose(lr_ts[::2], want, rtol=1e-12)
+    assert np.allclose(lr_ts, want, rtol=1e-12)
