@@ -110,7 +110,11 @@ __device__ __forceinline__ void cut8(const float (&v)[8], B16& b) {
     for (int q = 0; q < 4; ++q) cut_pair<kRelu>(v[2 * q], v[2 * q + 1], q, b);
 }
 
-// ---- the slot ring: one k-step (24 KiB) per slot, 3 slots, fed through registers (3 x 16 B per thread and k-step) -------------
+#ifndef MVS16_LDSDMA
+#define MVS16_LDSDMA 1     // 1: the weight stream reaches LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write);
+#endif                     // 0: through registers (three dwordx4 loads per thread and k-step, stored one k-step later)
+
+// ---- the slot ring: one k-step (24 KiB) per slot, 3 slots -------------------------------------------------------------------------
 constexpr int kR16Slots = 3, kR16SlotF4 = kS16SlotChunks * 64;               // float4 per slot
 constexpr int kS16PerView = kS16Hidden / 2;                                   // 24 k-steps: 3 ResNet blocks
 constexpr int kS16MaxPositions = 512;
@@ -123,7 +127,10 @@ struct Ring16 {
     const int* table;   // LDS: first chunk of every position of one tile
     int start_pf;       // first chunk of the position the next fetch loads (read one k-step ahead)
     int off;            // this thread's first 16 B inside a slot (tid * 16); + 8192, + 16384
+    int tid, wave;
+#if !MVS16_LDSDMA
     f32x4 stg[3];       // the fetched bytes on their way to LDS
+#endif
     u32x4 a0[3];        // A operands (3 pieces) of row block 0 of the CURRENT k-step, read during the previous one
 };
 
@@ -136,6 +143,30 @@ __device__ __forceinline__ int ring16_start_chunk(int p, int V, int l0_units) {
     return (kS16L0Pe + kS16L0Feat + kS16PerView + (p - per_view * V)) * kS16SlotChunks;
 }
 
+#if MVS16_LDSDMA
+// LDS-DMA of one position (24 chunks of 1 KiB starting at `start_chunk`) into ring slot `slot`: three wave-instructions per wave, each
+// moving 1 KiB (lane l: 16 bytes at wave base + 16 l); wave w of the 8 covers bytes [1024 w, 1024 w + 1024) of each 8 KiB third.
+__device__ __forceinline__ void ring16_dma(const Ring16& r, int start_chunk, int slot) {
+    const f32x4* src = r.w + (long)start_chunk * 64 + r.tid;
+    f32x4* dst = r.base + slot * kR16SlotF4 + 64 * r.wave;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 512 * i),
+                                         (__attribute__((address_space(3))) void*)(dst + 512 * i), 16, 0, 0);
+}
+
+// In the k-step at position p (slot c): position p + 2 goes into slot (c + 2) % 3 - the slot of position p - 1, which nobody reads any
+// more since the last barrier; the wait in front of the barrier at the k-step's end (ring16_next) lets it land before it is published.
+// Seven of the k-step's eight MFMA groups lie between the request and that wait.
+__device__ __forceinline__ void ring16_fetch(Ring16& r) {
+    int slot = r.c + 2;
+    slot = slot >= kR16Slots ? slot - kR16Slots : slot;
+    ring16_dma(r, r.start_pf, slot);
+    int pp = r.p + 3;                                                   // table entry the NEXT k-step's fetch needs
+    pp = pp >= r.P ? pp - r.P : pp;
+    r.start_pf = r.table[pp];
+}
+#else
 __device__ __forceinline__ void ring16_store(Ring16& r) {
     int slot = r.c + 2;
     slot = slot >= kR16Slots ? slot - kR16Slots : slot;
@@ -162,12 +193,17 @@ __device__ __forceinline__ void ring16_fetch(Ring16& r) {
     pp = pp >= r.P ? pp - r.P : pp;
     r.start_pf = r.table[pp];
 }
+#endif
 
 __device__ __forceinline__ const f32x4* ring16_cur(const Ring16& r) { return r.base + r.c * kR16SlotF4; }
 __device__ __forceinline__ const f32x4* ring16_nxt(const Ring16& r) { return r.base + (r.c + 1 == kR16Slots ? 0 : r.c + 1) * kR16SlotF4; }
 
 __device__ __forceinline__ void ring16_next(Ring16& r) {
+#if MVS16_LDSDMA
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     r.c = r.c + 1 == kR16Slots ? 0 : r.c + 1;
     r.p = r.p + 1 == r.P ? 0 : r.p + 1;
 }
@@ -407,6 +443,15 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
     ring.table = table;
     __syncthreads();                                                        // the position table is written
     ring.off = tid * 16;
+    ring.tid = tid;
+    ring.wave = wave;
+#if MVS16_LDSDMA
+    ring16_dma(ring, table[0], 0);                                          // prologue: positions 0 and 1 into slots 0 and 1
+    ring16_dma(ring, table[1], 1);
+    ring.start_pf = table[2];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#else
     for (int q = 0; q < 2; ++q) {                                           // prologue: positions 0 and 1 into slots 0 and 1
         ring16_load(ring, table[q]);
         ring.c = (q + kR16Slots - 2) % kR16Slots;                           // ring16_store writes slot (c + 2) % 3
@@ -416,6 +461,7 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
     ring16_load(ring, table[2]);
     ring.start_pf = table[3 % ring.P];
     __syncthreads();
+#endif
 #pragma unroll
     for (int q = 0; q < 3; ++q) ring.a0[q] = __builtin_bit_cast(u32x4, ring16_cur(ring)[q * 64 + lane]);
 
