@@ -360,6 +360,25 @@ int mvnerf_stash_fused_acts(const float* stash, int B, int V, int N, float* acts
 int mvnerf_adam_clip(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1, float beta2,
                      float eps, float clip, const unsigned char* update_mask, mvnerf_stream_t stream);
 
+/* ---- the per-point part of GraspReadout (delta_ngf/layers.py:8-42: four Dense(128 -> 64) + elu on the four fused trunk activations,
+ * concatenation, Dense(256 -> 64) + elu - what LanguageNeRF._call feeds to the per-pose ResNet blocks, lmvnerf/model_v4.py:261-263) as three
+ * fused passes: its value, its vector-Jacobian product and the derivative of that product, which the nested GradientTape of
+ * LanguageNeRF.train_step (lmvnerf/model_v4.py:290-322) needs.  fp32, v_mfma_f32_32x32x2_f32, one wavefront per 32 points, row-major (N, F)
+ * tensors, 16-byte aligned.  w4: the four Dense kernels (4, 64, 128) [out, in] (torch layout), wc: (64, 256), b4: (4, 64), bc: (64). */
+size_t mvnerf_grasp_head_packed_floats(void);
+int mvnerf_grasp_head_pack(const float* w4, const float* wc, float* packed, mvnerf_stream_t stream);
+/* acts (4, N, 128) -> c (N, 256) = [elu(W_k a_k + b_k)] and y (N, 64) = elu(W_c c + b_c). */
+int mvnerf_grasp_head_fwd(const float* acts, const float* packed, const float* b4, const float* bc, long N, float* c, float* y,
+                          mvnerf_stream_t stream);
+/* g_y (N, 64) = dL/dy -> g_acts (4, N, 128) = dL/d(acts), and the per-point cotangents g_v (N, 64), q (N, 256), g_u (N, 256) from which the
+ * weight gradients are skinny GEMMs: dW_c = g_v^T c, db_c = sum g_v, dW_k = g_u[:, 64k:64k+64]^T a_k, db_k = sum g_u[:, 64k:64k+64]. */
+int mvnerf_grasp_head_vjp(const float* g_y, const float* c, const float* y, const float* packed, long N, float* g_v, float* q, float* g_u,
+                          float* g_acts, mvnerf_stream_t stream);
+/* The derivative of mvnerf_grasp_head_vjp: t_acts (4, N, 128) = dL/d(g_acts) -> out_gy (N, 64) = dL/d(g_y) and r (N, 256), m (N, 64),
+ * p (N, 256) with dL/dW_k = g_u_k^T t_k + p_k^T a_k, dL/db_k = sum p_k, dL/dW_c = g_v^T r + m^T c, dL/db_c = sum m. */
+int mvnerf_grasp_head_vjp_bwd(const float* t_acts, const float* g_y, const float* c, const float* y, const float* q, const float* packed, long N,
+                              float* out_gy, float* r, float* m, float* p, mvnerf_stream_t stream);
+
 /* ---- the whole training step behind one call (MVVNeRFRenderer.train_step, model_v0.py:186-197: GradientTape over call(),
  * loss = MSE(y, rgb) + MSE(y, fine_rgb) :193, gradients :194, optimize() :195 = nerf_utils.py:8-12) ----
  * The matching `_bwd` of mvnerf_render_fwd: a host in any language takes a training step with these entry points and

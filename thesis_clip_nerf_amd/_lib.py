@@ -95,6 +95,11 @@ SIGNATURES = {
     'mvnerf_field_backward_table': (c_int, [c_void_p] * 14 + [c_int] * 6 + [c_void_p] * 5),
     'mvnerf_adam_clip': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float,
                                  c_void_p, c_void_p]),
+    'mvnerf_grasp_head_packed_floats': (c_size_t, []),
+    'mvnerf_grasp_head_pack': (c_int, [c_void_p] * 4),
+    'mvnerf_grasp_head_fwd': (c_int, [c_void_p] * 4 + [c_long] + [c_void_p] * 3),
+    'mvnerf_grasp_head_vjp': (c_int, [c_void_p] * 4 + [c_long] + [c_void_p] * 5),
+    'mvnerf_grasp_head_vjp_bwd': (c_int, [c_void_p] * 6 + [c_long] + [c_void_p] * 5),
     'mvnerf_train_workspace_bytes': (c_size_t, [c_int] * 8),
     'mvnerf_loss_and_grads': (c_int, [ctypes.POINTER(TrainCall), c_void_p]),
     'mvnerf_apply_gradients': (c_int, [ctypes.POINTER(TrainCall), ctypes.POINTER(AdamState), c_void_p]),

@@ -110,6 +110,9 @@ __device__ __forceinline__ void cut8(const float (&v)[8], B16& b) {
     for (int q = 0; q < 4; ++q) cut_pair<kRelu>(v[2 * q], v[2 * q + 1], q, b);
 }
 
+#ifndef MVS16_ORDER
+#define MVS16_ORDER 0      // order of the six products of a block (A/B experiment, see kstep16)
+#endif
 #ifndef MVS16_LDSDMA
 #define MVS16_LDSDMA 1     // 1: the weight stream reaches LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write);
 #endif                     // 0: through registers (three dwordx4 loads per thread and k-step, stored one k-step later)
@@ -276,6 +279,21 @@ __device__ __forceinline__ void kstep16(Ring16& ring, int lane, int g, const B16
                 bv = bv_new;
             }
         }
+#if MVS16_ORDER == 1
+        // the A operand changes as rarely as possible: a2 (x2), a1 (x4), a0 (x6); per chain a2p1, a1p2, a1p1, a0p3, a0p2, a0p1
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma1632(a[2], b[cb].p1, acc[rb][cb]);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma1632(a[1], b[cb].p2, acc[rb][cb]);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma1632(a[1], b[cb].p1, acc[rb][cb]);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma1632(a[0], b[cb].p3, acc[rb][cb]);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma1632(a[0], b[cb].p2, acc[rb][cb]);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma1632(a[0], b[cb].p1, acc[rb][cb]);
+#else
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma1632(a[2], b[cb].p1, acc[rb][cb]);
 #pragma unroll
@@ -288,6 +306,7 @@ __device__ __forceinline__ void kstep16(Ring16& ring, int lane, int g, const B16
         for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma1632(a[0], b[cb].p2, acc[rb][cb]);
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma1632(a[0], b[cb].p1, acc[rb][cb]);
+#endif
         // issue order inside the group: the first MFMA (its operands were requested one group ago), the LDS reads of the next group
         // (and the bias row), then vector instructions / MFMA alternating
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);

@@ -64,6 +64,15 @@ hipError_t launch_pack_net_split16(const float* net_keras, void* packed_split16,
 bool field_eval_split16_supports(const FieldParams& p);
 hipError_t launch_field_eval_split16(const FieldParams& p, const void* packed_split16, hipStream_t stream);
 
+// grasp_head.hip: the per-point part of GraspReadout (value, VJP, derivative of the VJP)
+size_t grasp_head_packed_floats();
+hipError_t launch_grasp_head_pack(const float* w4, const float* wc, float* packed, hipStream_t st);
+hipError_t launch_grasp_head_fwd(const float* acts, const float* packed, const float* b4, const float* bc, long N, float* c, float* y, hipStream_t st);
+hipError_t launch_grasp_head_vjp(const float* g_y, const float* c, const float* y, const float* packed, long N, float* g_v, float* q, float* g_u,
+                                 float* g_acts, hipStream_t st);
+hipError_t launch_grasp_head_vjp_bwd(const float* t_acts, const float* g_y, const float* c, const float* y, const float* q, const float* packed,
+                                     long N, float* out_gy, float* r, float* m, float* p, hipStream_t st);
+
 hipError_t launch_get_rays(const double* m9, const double* origin3, const float* u, const float* v, int n_rays,
                            int width, int normalize, float* rays_o, float* rays_d, double* rays_d64,
                            hipStream_t stream);

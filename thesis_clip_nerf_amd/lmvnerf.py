@@ -175,6 +175,64 @@ def _wide_linear(lin, x):
     return y.reshape(*x.shape[:-1], lin.out_features)
 
 
+# ---- the per-point part of the read-out as fused HIP passes (csrc/grasp_head.hip) ----------------------------------------------------
+def _gtn(g, a):
+    """g (M,N)^T @ a (M,K) -> (N,K) on mvnerf_gemm_tn where it takes the shape (M = the number of query points)."""
+    if _tn_skinny(g.shape[0], g.shape[1], a.shape[1]):
+        return ops.gemm_tn(g.contiguous(), a.contiguous())
+    return g.t() @ a
+
+
+class _HeadVJP(torch.autograd.Function):
+    """The vector-Jacobian product of the fused head as a differentiable function of its cotangent and of the weights: forward =
+    mvnerf_grasp_head_vjp (+ the weight gradients as skinny GEMMs), backward = mvnerf_grasp_head_vjp_bwd - what the nested tape of
+    LanguageNeRF.train_step needs (model_v4.py:290-322).  The activations' own second derivative is not formed (they depend on the pose
+    only, which is not trained); cotangents on the weight-gradient outputs are refused."""
+
+    @staticmethod
+    def forward(ctx, g_y, acts, c, y, w4, b4, wc, bc, packed):
+        g_y = g_y.contiguous()
+        g_v, q, g_u, g_acts = ops.grasp_head_vjp(g_y, c, y, packed)
+        d_wc, d_bc = _gtn(g_v, c), g_v.sum(0)
+        d_w4 = torch.stack([_gtn(g_u[:, 64 * k:64 * k + 64], acts[k]) for k in range(4)])
+        d_b4 = g_u.sum(0).reshape(4, 64)
+        ctx.save_for_backward(g_y, acts, c, y, q, g_v, g_u, packed)
+        ctx.set_materialize_grads(False)
+        return g_acts, d_w4, d_b4, d_wc, d_bc
+
+    @staticmethod
+    def backward(ctx, t_acts, *weight_cotangents):
+        if any(t is not None for t in weight_cotangents):
+            raise NotImplementedError('_HeadVJP: derivatives of the weight gradients are not built (LanguageNeRF.train_step does not take them)')
+        if t_acts is None:
+            return (None,) * 9
+        g_y, acts, c, y, q, g_v, g_u, packed = ctx.saved_tensors
+        out_gy, r, m, p_ = ops.grasp_head_vjp_bwd(t_acts.contiguous(), g_y, c, y, q, packed)
+        d_w4 = torch.stack([_gtn(g_u[:, 64 * k:64 * k + 64], t_acts[k]) + _gtn(p_[:, 64 * k:64 * k + 64], acts[k]) for k in range(4)])
+        d_b4 = p_.sum(0).reshape(4, 64)
+        d_wc = _gtn(g_v, r) + _gtn(m, c)
+        d_bc = m.sum(0)
+        return out_gy, None, None, None, d_w4, d_b4, d_wc, d_bc, None
+
+
+class _HeadFn(torch.autograd.Function):
+    """acts (4,N,128) -> (N,64): four Dense(128 -> 64) + elu, concatenation, Dense(256 -> 64) + elu in ONE launch (mvnerf_grasp_head_fwd);
+    its backward is _HeadVJP, itself differentiable."""
+
+    @staticmethod
+    def forward(ctx, acts, w4, b4, wc, bc):
+        acts, w4, b4, wc, bc = (t.contiguous() for t in (acts, w4, b4, wc, bc))
+        packed = ops.grasp_head_pack(w4, wc)
+        c, y = ops.grasp_head_fwd(acts, packed, b4, bc)
+        ctx.save_for_backward(acts, c, y, w4, b4, wc, bc, packed)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        acts, c, y, w4, b4, wc, bc, packed = ctx.saved_tensors
+        return _HeadVJP.apply(g_y, acts, c, y, w4, b4, wc, bc, packed)
+
+
 def _he_normal_(w):
     fan_in = w.shape[1]
     nn.init.trunc_normal_(w, std=math.sqrt(2.0 / fan_in) / 0.87962566103423978, a=-2 * math.sqrt(2.0 / fan_in) / 0.87962566103423978,
@@ -216,11 +274,24 @@ class GraspReadout(nn.Module):
         if self.output_layer.bias is not None:
             nn.init.zeros_(self.output_layer.bias)
 
+    fused_head = True      # the per-point layers as fused HIP passes (csrc/grasp_head.hip); False: Linear by Linear (torch + gemm_ops)
+
     def forward(self, acts):
-        """acts: 4 x (B, np, n5, 128) -> (B, np)."""
-        ds = [nn.functional.elu(_wide_linear(lin, a)) for lin, a in zip(self.activation_downscale, acts)]
-        x = nn.functional.elu(_wide_linear(self.combined_activation_downscale, torch.cat(ds, -1)))
-        x = x.reshape(x.shape[0], x.shape[1], -1)                                # 'b np n5 d -> b np (n5 d)'
+        """acts: 4 x (B, np, n5, 128), or the same stacked as one (4, B, np, n5, 128) tensor -> (B, np)."""
+        stacked = acts if isinstance(acts, torch.Tensor) else None
+        first = acts[0]
+        b, n_p, n5 = first.shape[0], first.shape[1], first.shape[2]
+        if self.fused_head and first.is_cuda and first.dtype == torch.float32:
+            a = (stacked if stacked is not None else torch.stack(list(acts))).reshape(N_FUSED, -1, 128)
+            w4 = torch.stack([lin.weight for lin in self.activation_downscale])
+            b4 = torch.stack([lin.bias for lin in self.activation_downscale])
+            x = _HeadFn.apply(a, w4, b4, self.combined_activation_downscale.weight, self.combined_activation_downscale.bias)
+            x = x.reshape(b, n_p, n5 * 64)                                       # 'b np n5 d -> b np (n5 d)'
+        else:
+            acts = list(acts.unbind(0)) if stacked is not None else acts
+            ds = [nn.functional.elu(_wide_linear(lin, a)) for lin, a in zip(self.activation_downscale, acts)]
+            x = nn.functional.elu(_wide_linear(self.combined_activation_downscale, torch.cat(ds, -1)))
+            x = x.reshape(x.shape[0], x.shape[1], -1)                            # 'b np n5 d -> b np (n5 d)'
         x = self.block_1(self.block_0(x))
         return self.output_layer(torch.relu(x))[..., 0]
 
@@ -366,7 +437,7 @@ class LanguageNeRF(nn.Module):
         points, dirs = self._query_points(transforms)
         acts = TrunkField.apply(points, dirs, state)                                     # (4, B, np*n5, 128)
         acts = acts.reshape(N_FUSED, transforms.shape[0], n_points, self.n_transforms_to_check, 128)
-        return self.grasp_readout(list(acts.unbind(0)))
+        return self.grasp_readout(acts)
 
     def infer(self, inputs, transforms, n_points_infer, batched_features, compute_dtype='f32'):
         """model_v4.py:208-209.  compute_dtype='bf16' evaluates the trunk on the bf16 MFMA kernel (no gradients there)."""

@@ -545,6 +545,69 @@ def field_backward(rays_o, rays_d, z, images, features, intrinsics, extrinsics_i
     return scratch
 
 
+# ---- the per-point part of GraspReadout as fused passes (csrc/grasp_head.hip; delta_ngf/layers.py:8-42, lmvnerf/model_v4.py:261-322) ----
+def grasp_head_pack(w4, wc):
+    """The four Dense(128 -> 64) kernels w4 (4,64,128) and the Dense(256 -> 64) kernel wc (64,256), torch [out, in] layout -> MFMA operand image."""
+    _chk(w4, 'w4', shape=(4, 64, 128))
+    _chk(wc, 'wc', shape=(64, 256))
+    out = torch.empty(int(_lib.lib().mvnerf_grasp_head_packed_floats()), dtype=torch.float32, device=w4.device)
+    with torch.cuda.device(w4.device):
+        _lib.check(_lib.lib().mvnerf_grasp_head_pack(_p(w4), _p(wc), _p(out), _stream(w4)), 'grasp_head_pack')
+    return out
+
+
+def grasp_head_fwd(acts, packed, b4, bc):
+    """acts (4,N,128) -> c (N,256) = [elu(W_k a_k + b_k)], y (N,64) = elu(W_c c + b_c)."""
+    _chk(acts, 'acts', shape=(4, None, 128))
+    n = acts.shape[1]
+    _chk(packed, 'packed', shape=(int(_lib.lib().mvnerf_grasp_head_packed_floats()),))
+    _chk(b4, 'b4', shape=(4, 64))
+    _chk(bc, 'bc', shape=(64,))
+    c = torch.empty((n, 256), dtype=torch.float32, device=acts.device)
+    y = torch.empty((n, 64), dtype=torch.float32, device=acts.device)
+    with torch.cuda.device(acts.device):
+        _lib.check(_lib.lib().mvnerf_grasp_head_fwd(_p(acts), _p(packed), _p(b4), _p(bc), n, _p(c), _p(y), _stream(acts)), 'grasp_head_fwd')
+    return c, y
+
+
+def grasp_head_vjp(g_y, c, y, packed):
+    """g_y (N,64) -> g_v (N,64), q (N,256), g_u (N,256), g_acts (4,N,128)."""
+    _chk(g_y, 'g_y', shape=(None, 64))
+    n = g_y.shape[0]
+    _chk(c, 'c', shape=(n, 256))
+    _chk(y, 'y', shape=(n, 64))
+    _chk(packed, 'packed', shape=(int(_lib.lib().mvnerf_grasp_head_packed_floats()),))
+    dev = g_y.device
+    g_v = torch.empty((n, 64), dtype=torch.float32, device=dev)
+    q = torch.empty((n, 256), dtype=torch.float32, device=dev)
+    g_u = torch.empty((n, 256), dtype=torch.float32, device=dev)
+    g_acts = torch.empty((4, n, 128), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().mvnerf_grasp_head_vjp(_p(g_y), _p(c), _p(y), _p(packed), n, _p(g_v), _p(q), _p(g_u), _p(g_acts), _stream(g_y)),
+                   'grasp_head_vjp')
+    return g_v, q, g_u, g_acts
+
+
+def grasp_head_vjp_bwd(t_acts, g_y, c, y, q, packed):
+    """t_acts (4,N,128) = dL/d(g_acts) -> out_gy (N,64) = dL/d(g_y), r (N,256), m (N,64), p (N,256) (see include/mvnerf_hip.h)."""
+    _chk(t_acts, 't_acts', shape=(4, None, 128))
+    n = t_acts.shape[1]
+    _chk(g_y, 'g_y', shape=(n, 64))
+    _chk(c, 'c', shape=(n, 256))
+    _chk(y, 'y', shape=(n, 64))
+    _chk(q, 'q', shape=(n, 256))
+    _chk(packed, 'packed', shape=(int(_lib.lib().mvnerf_grasp_head_packed_floats()),))
+    dev = t_acts.device
+    out_gy = torch.empty((n, 64), dtype=torch.float32, device=dev)
+    r = torch.empty((n, 256), dtype=torch.float32, device=dev)
+    m = torch.empty((n, 64), dtype=torch.float32, device=dev)
+    p_ = torch.empty((n, 256), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().mvnerf_grasp_head_vjp_bwd(_p(t_acts), _p(g_y), _p(c), _p(y), _p(q), _p(packed), n, _p(out_gy), _p(r), _p(m),
+                                                        _p(p_), _stream(t_acts)), 'grasp_head_vjp_bwd')
+    return out_gy, r, m, p_
+
+
 def train_workspace_bytes(b, v, r, s, h, w, use_tables, want_d_features):
     return int(_lib.lib().mvnerf_train_workspace_bytes(int(b), int(v), int(r), int(s), int(h), int(w), int(bool(use_tables)),
                                                        int(bool(want_d_features))))
