@@ -59,22 +59,31 @@ __global__ void grasp_head_pack_kernel(const float* __restrict__ w4 /*(4,64,128)
     dst[idx] = val;
 }
 
-// acc[nbo] += A^T-product over KB input blocks held in accumulator order
+// acc[nbo] += A^T-product over KB input blocks held in accumulator order.  The A chunks of step (kb, t) + 1 are requested before the
+// MFMAs of step (kb, t) are issued and pinned there (the weights come from L2: a round trip is as long as a step's 4 x NBO MFMAs).
 template <int KB, int NBO>
 __device__ __forceinline__ void dense_blocks(const float* __restrict__ packed, int lane, const f32x16 (&in)[KB], f32x16 (&acc)[NBO]) {
     const f32x4* w = reinterpret_cast<const f32x4*>(packed) + lane;
+    f32x4 a[NBO], an[NBO];
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
+    for (int nbo = 0; nbo < NBO; ++nbo) a[nbo] = w[nbo * 64];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x4 a[NBO];
+    for (int st = 0; st < KB * 4; ++st) {
+        const int kb = st >> 2, t = st & 3;
+        if (st + 1 < KB * 4) {
 #pragma unroll
-            for (int nbo = 0; nbo < NBO; ++nbo) a[nbo] = w[((kb * 4 + t) * NBO + nbo) * 64];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int nbo = 0; nbo < NBO; ++nbo) acc[nbo] = mfma(a[nbo][e], in[kb][4 * t + e], acc[nbo]);
+            for (int nbo = 0; nbo < NBO; ++nbo) an[nbo] = w[((st + 1) * NBO + nbo) * 64];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int nbo = 0; nbo < NBO; ++nbo) acc[nbo] = mfma(a[nbo][e], in[kb][4 * t + e], acc[nbo]);
+        if (st + 1 < KB * 4) {
+#pragma unroll
+            for (int nbo = 0; nbo < NBO; ++nbo) a[nbo] = an[nbo];
+        }
+    }
 }
 
 // block nb (32 features) of row `point` of a row-major (N, F) tensor, in accumulator order: lane (j, h) register 4q + c = feature
