@@ -18,7 +18,7 @@
 // One k-step = 8 row blocks x 2 column blocks x 6 products = 96 MFMAs of 16 cycles (= two of the old k-steps); its weights are
 // one 24 KiB ring slot (8 row blocks x 3 pieces x 1 KiB); 3 slots; half as many barriers per tile.
 //
-// Built for inference (no stash); the training forward (kStash) stays on field_eval_split_kernel.
+// Inference and, since the end of round 3, the training forward (kStash: the 13 pre-activation tensors go to the stash in tile layout).
 #include <hip/hip_runtime.h>
 
 #include <mutex>
@@ -131,9 +131,7 @@ struct Ring16 {
     int start_pf;       // first chunk of the position the next fetch loads (read one k-step ahead)
     int off;            // this thread's first 16 B inside a slot (tid * 16); + 8192, + 16384
     int tid, wave;
-#if !MVS16_LDSDMA
-    f32x4 stg[3];       // the fetched bytes on their way to LDS
-#endif
+    f32x4 stg[3];       // register-staged ring only (kDma = false): the fetched bytes on their way to LDS
     u32x4 a0[3];        // A operands (3 pieces) of row block 0 of the CURRENT k-step, read during the previous one
 };
 
@@ -146,7 +144,6 @@ __device__ __forceinline__ int ring16_start_chunk(int p, int V, int l0_units) {
     return (kS16L0Pe + kS16L0Feat + kS16PerView + (p - per_view * V)) * kS16SlotChunks;
 }
 
-#if MVS16_LDSDMA
 // LDS-DMA of one position (24 chunks of 1 KiB starting at `start_chunk`) into ring slot `slot`: three wave-instructions per wave, each
 // moving 1 KiB (lane l: 16 bytes at wave base + 16 l); wave w of the 8 covers bytes [1024 w, 1024 w + 1024) of each 8 KiB third.
 __device__ __forceinline__ void ring16_dma(const Ring16& r, int start_chunk, int slot) {
@@ -158,18 +155,6 @@ __device__ __forceinline__ void ring16_dma(const Ring16& r, int start_chunk, int
                                          (__attribute__((address_space(3))) void*)(dst + 512 * i), 16, 0, 0);
 }
 
-// In the k-step at position p (slot c): position p + 2 goes into slot (c + 2) % 3 - the slot of position p - 1, which nobody reads any
-// more since the last barrier; the wait in front of the barrier at the k-step's end (ring16_next) lets it land before it is published.
-// Seven of the k-step's eight MFMA groups lie between the request and that wait.
-__device__ __forceinline__ void ring16_fetch(Ring16& r) {
-    int slot = r.c + 2;
-    slot = slot >= kR16Slots ? slot - kR16Slots : slot;
-    ring16_dma(r, r.start_pf, slot);
-    int pp = r.p + 3;                                                   // table entry the NEXT k-step's fetch needs
-    pp = pp >= r.P ? pp - r.P : pp;
-    r.start_pf = r.table[pp];
-}
-#else
 __device__ __forceinline__ void ring16_store(Ring16& r) {
     int slot = r.c + 2;
     slot = slot >= kR16Slots ? slot - kR16Slots : slot;
@@ -186,27 +171,35 @@ __device__ __forceinline__ void ring16_load(Ring16& r, int start_chunk) {
     r.stg[2] = *reinterpret_cast<const f32x4*>(src + 16384);
 }
 
-// In the k-step at position p (slot c): store what the previous k-step loaded (position p + 2) into slot (c + 2) % 3 - the slot of
-// position p - 1, which nobody reads any more since the last barrier - and load position p + 3; the barrier at the k-step's end
-// publishes the store.  A whole k-step of matrix work lies between a load and the store that waits for it.
+// The weight fetch of the k-step at position p (slot c), issued behind its first MFMA group.
+// kDma (inference): position p + 2 goes straight into slot (c + 2) % 3 by LDS-DMA - the slot of position p - 1, which nobody reads any
+//   more since the last barrier; the vmcnt(0) in front of the barrier at the k-step's end (ring16_next) lets it land before it is published;
+//   seven of the k-step's eight MFMA groups lie between the request and that wait.  No staging registers, no ds_write.
+// !kDma (training forward): through registers - store what the previous k-step loaded (position p + 2), load position p + 3 - because vmcnt
+//   retires in order: behind the stash's buffer_stores a vmcnt(0) per k-step would wait for 16 KiB of HBM writes per wave, whereas the
+//   staged loads are older than the stores that follow them.
+template <bool kDma>
 __device__ __forceinline__ void ring16_fetch(Ring16& r) {
-    ring16_store(r);
-    ring16_load(r, r.start_pf);
-    int pp = r.p + 4;                                                   // table entry the NEXT k-step's fetch needs
+    if (kDma) {
+        int slot = r.c + 2;
+        slot = slot >= kR16Slots ? slot - kR16Slots : slot;
+        ring16_dma(r, r.start_pf, slot);
+    } else {
+        ring16_store(r);
+        ring16_load(r, r.start_pf);
+    }
+    int pp = r.p + (kDma ? 3 : 4);                                      // table entry the NEXT k-step's fetch needs
     pp = pp >= r.P ? pp - r.P : pp;
     r.start_pf = r.table[pp];
 }
-#endif
 
 __device__ __forceinline__ const f32x4* ring16_cur(const Ring16& r) { return r.base + r.c * kR16SlotF4; }
 __device__ __forceinline__ const f32x4* ring16_nxt(const Ring16& r) { return r.base + (r.c + 1 == kR16Slots ? 0 : r.c + 1) * kR16SlotF4; }
 
+template <bool kDma>
 __device__ __forceinline__ void ring16_next(Ring16& r) {
-#if MVS16_LDSDMA
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
+    if (kDma) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     r.c = r.c + 1 == kR16Slots ? 0 : r.c + 1;
     r.p = r.p + 1 == r.P ? 0 : r.p + 1;
 }
@@ -243,7 +236,7 @@ __device__ __forceinline__ void apply_bias_row(f32x4 (&row)[2], const f32x4& bv)
 //            longer needed, takes the bias work of the layer boundary (tail_bias: in[rb][cb] += bias row, or = bias row), one row
 //            block per group.  With it no vector work of a layer boundary is left outside the MFMA shadow.
 //   kMode 0: nothing.
-template <bool kRelu, int kMode, bool kTailAdd>
+template <bool kRelu, int kMode, bool kTailAdd, bool kDma>
 __device__ __forceinline__ void kstep16(Ring16& ring, int lane, int g, const B16 (&b)[2], const float (&nv)[2][8], B16 (&bn)[2], f32x4 (&acc)[8][2],
                                         f32x4 (&in)[8][2], const float* __restrict__ tail_bias) {
     const f32x4* cur = ring16_cur(ring) + lane;
@@ -321,7 +314,7 @@ __device__ __forceinline__ void kstep16(Ring16& ring, int lane, int g, const B16
         if (kMode == 2) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (rb == 0) {   // the weight loads of two k-steps ahead
-            ring16_fetch(ring);
+            ring16_fetch<kDma>(ring);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -363,6 +356,7 @@ __device__ __forceinline__ void first_operand_s16(const f32x4 (&in)[8][2], B16 (
 #endif                     //    cut, bias rows) stays between the layers.  Measured (profiles/r03_ab_tail*.log): 1 is 3-5 % SLOWER - see DESIGN.md 4.0
 
 // the plain form: acc += W^T relu(in), first operand cut at the layer's head
+template <bool kDma>
 __device__ __forceinline__ void dense128_s16_plain(Ring16& ring, int lane, int g, f32x4 (&in)[8][2], f32x4 (&acc)[8][2]) {
     B16 b[2], bn[2];
     first_operand_s16(in, b);
@@ -373,11 +367,11 @@ __device__ __forceinline__ void dense128_s16_plain(Ring16& ring, int lane, int g
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int q = 0; q < 8; ++q) nv[cb][q] = t < 3 ? in[2 * (t + 1) + (q >> 2)][cb][q & 3] : 0.0f;
-        if (t < 3) kstep16<true, 1, false>(ring, lane, g, b, nv, bn, acc, in, nullptr);
-        else kstep16<true, 0, false>(ring, lane, g, b, nv, bn, acc, in, nullptr);
+        if (t < 3) kstep16<true, 1, false, kDma>(ring, lane, g, b, nv, bn, acc, in, nullptr);
+        else kstep16<true, 0, false, kDma>(ring, lane, g, b, nv, bn, acc, in, nullptr);
         b[0] = bn[0];
         b[1] = bn[1];
-        ring16_next(ring);
+        ring16_next<kDma>(ring);
     }
 }
 template <bool kAdd>
@@ -394,11 +388,11 @@ __device__ __forceinline__ void dense128_s16(Ring16& ring, int lane, int g, f32x
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int q = 0; q < 8; ++q) nv[cb][q] = t < 3 ? in[2 * (t + 1) + (q >> 2)][cb][q & 3] : 0.0f;
-        if (t < 3) kstep16<true, 1, false>(ring, lane, g, b, nv, bn, acc, in, nullptr);
-        else kstep16<true, 2, kTailAdd>(ring, lane, g, b, nv, bn, acc, in, tail_bias);
+        if (t < 3) kstep16<true, 1, false, true>(ring, lane, g, b, nv, bn, acc, in, nullptr);
+        else kstep16<true, 2, kTailAdd, true>(ring, lane, g, b, nv, bn, acc, in, tail_bias);
         b[0] = bn[0];
         b[1] = bn[1];
-        ring16_next(ring);
+        ring16_next<true>(ring);
     }
 }
 
@@ -425,6 +419,26 @@ __device__ __forceinline__ void bias16(const float* __restrict__ bperm, int g, f
 
 constexpr int kS16StageRowBytes = 256;      // per staged sample row: 64 fp32 channels
 
+// Training forward: one activation tensor of a tile into the stash, tile layout [tile][feature][32 samples] (mvnerf_mfma.h: the layout
+// the backward kernels read).  Lane (n, g) holds features 16 rb + 4g + i of samples 16 cb + n: per (rb, i, cb) a wave-instruction writes
+// four 64-byte runs (one feature row half each); one address VGPR, row block in the scalar offset, (i, cb) in the immediate; non-temporal
+// as store_tl (the stash is written once and read a whole pass later).
+__device__ __forceinline__ void store_tl16(float* __restrict__ base, long tile, int n, int g, const f32x4 (&x)[8][2]) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFF, 0x00020000);
+    const int voff = (4 * g * 32 + n) * 4;
+    const int tile_off = (int)((unsigned)tile * 16384u);
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const float val = x[rb][cb][i];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, val), rsrc, voff + (i * 32 + 16 * cb) * 4,
+                                                      tile_off + rb * 2048, MV_STASH_AUX);
+            }
+}
+
 struct SampleGeo {
     long g;           // global sample index (clamped)
     int ray, sidx, b;
@@ -435,9 +449,12 @@ struct SampleGeo {
 // kProj: layer 0's feature rows come from the fp32 texel table (project_texels_kernel, field_eval.hip).
 // kAux: the optional outputs (tap indices, pixel coordinates, embedding, the 8 complete_output activations) are compiled in; the plain
 // render variant carries none of the per-sample row indices they need through the tile (fewer spilled registers).
-template <bool kMultiView, bool kProj, bool kAux>
+// kStash (training forward): the trunk's 13 pre-activation tensors also go to HBM (p.stash / p.stash_fused, mvnerf_kernels.h), exactly
+// the slots field_eval_split_kernel<.., kStash> writes.
+template <bool kMultiView, bool kProj, bool kAux, bool kStash>
 __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams p, const f32x4* __restrict__ wsplit) {
     constexpr int kW = 8;
+    constexpr bool kDma = MVS16_LDSDMA && !kStash;                           // see ring16_fetch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s16[];
     constexpr int kRingBytes = kR16Slots * kR16SlotF4 * 16;                 // 72 KiB
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
@@ -464,23 +481,22 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
     ring.off = tid * 16;
     ring.tid = tid;
     ring.wave = wave;
-#if MVS16_LDSDMA
-    ring16_dma(ring, table[0], 0);                                          // prologue: positions 0 and 1 into slots 0 and 1
-    ring16_dma(ring, table[1], 1);
-    ring.start_pf = table[2];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#else
-    for (int q = 0; q < 2; ++q) {                                           // prologue: positions 0 and 1 into slots 0 and 1
-        ring16_load(ring, table[q]);
-        ring.c = (q + kR16Slots - 2) % kR16Slots;                           // ring16_store writes slot (c + 2) % 3
-        ring16_store(ring);
+    if (kDma) {
+        ring16_dma(ring, table[0], 0);                                      // prologue: positions 0 and 1 into slots 0 and 1
+        ring16_dma(ring, table[1], 1);
+        ring.start_pf = table[2];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        for (int q = 0; q < 2; ++q) {                                       // prologue: positions 0 and 1 into slots 0 and 1
+            ring16_load(ring, table[q]);
+            ring.c = (q + kR16Slots - 2) % kR16Slots;                       // ring16_store writes slot (c + 2) % 3
+            ring16_store(ring);
+        }
+        ring.c = 0;
+        ring16_load(ring, table[2]);
+        ring.start_pf = table[3 % ring.P];
     }
-    ring.c = 0;
-    ring16_load(ring, table[2]);
-    ring.start_pf = table[3 % ring.P];
     __syncthreads();
-#endif
 #pragma unroll
     for (int q = 0; q < 3; ++q) ring.a0[q] = __builtin_bit_cast(u32x4, ring16_cur(ring)[q * 64 + lane]);
 
@@ -624,10 +640,10 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) nv[cb][q] = pe[cb][8 + q];
-                kstep16<false, 1, false>(ring, lane, g, bq, nv, bqn, x, x, nullptr);
-                ring16_next(ring);
-                kstep16<false, 0, false>(ring, lane, g, bqn, nv, bq, x, x, nullptr);
-                ring16_next(ring);
+                kstep16<false, 1, false, kDma>(ring, lane, g, bq, nv, bqn, x, x, nullptr);
+                ring16_next<kDma>(ring);
+                kstep16<false, 0, false, kDma>(ring, lane, g, bqn, nv, bq, x, x, nullptr);
+                ring16_next<kDma>(ring);
             }
 
             // ---- layer 0's 256 feature rows through the wave-private fp32 stage ----
@@ -700,13 +716,16 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
 #pragma unroll
                             for (int q = 0; q < 8; ++q) nv[cb][q] = 0.0f;
                         }
-                        kstep16<false, 0, false>(ring, lane, gl, bq, nv, bqn, x, x, nullptr);
-                        ring16_next(ring);
+                        kstep16<false, 0, false, kDma>(ring, lane, gl, bq, nv, bqn, x, x, nullptr);
+                        ring16_next<kDma>(ring);
                     }
                 }
             }
 
             const long vslot = (long)p.B * p.V * p.R * p.S * 128;
+            // training mode: view tile index (all 32 samples of a tile share b because R*S % 32 == 0 when V > 1)
+            const long vtile = kMultiView ? ((long)(sg[0].b * p.V + v) * (p.n_tiles / p.B) + (tile - (long)sg[0].b * (p.n_tiles / p.B))) : tile;
+            if (kStash && tile_ok) store_tl16(p.stash, vtile, n, g, x);                      // per-view slot 0: layer-0 output
             auto store_acc16 = [&](float* base, const long (&rows)[2]) {
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
@@ -733,9 +752,12 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
                 dense128_s16<false>(ring, lane, g, hid, x, bop, next_b1);
 #else
                 bias16<false>(bias1, g, hid);
-                dense128_s16_plain(ring, lane, g, x, hid);
+                dense128_s16_plain<kDma>(ring, lane, g, x, hid);
+                if (kStash && tile_ok) store_tl16(p.stash + (1 + 2 * bi) * p.stash_stride, vtile, n, g, hid);
                 bias16<true>(bias1 + 128, g, x);
-                dense128_s16_plain(ring, lane, g, hid, x);
+                dense128_s16_plain<kDma>(ring, lane, g, hid, x);
+                // (per-view slot 6 = x3 is not written: nothing reads it, as in field_eval_split_kernel)
+                if (kStash && tile_ok && bi < 2) store_tl16(p.stash + (2 + 2 * bi) * p.stash_stride, vtile, n, g, x);
 #endif
                 if (kAux && p.acts_view) store_acc16(p.acts_view + (bi + 1) * vslot, vrow);
             }
@@ -777,6 +799,7 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
                 }
         };
         if (kAux && p.acts_fused) store_fused16(p.acts_fused);               // complete_output: the view mean
+        if (kStash && tile_ok) store_tl16(p.stash_fused, tile, n, g, x);      // fused slot 0: the view mean
         // ---- 24 k-steps: fusion blocks ----
 #if MVS16_TAIL
         if (kMultiView) first_operand_s16(x, bop);                           // the view mean is new; V = 1: bop already is the cut of relu(x)
@@ -789,9 +812,11 @@ __global__ __launch_bounds__(512, 2) void field_eval_split16_kernel(FieldParams 
             dense128_s16<false>(ring, lane, g, hid, x, bop, bi < 5 ? bias1 + 256 : nullptr);
 #else
             bias16<false>(bias1, g, hid);
-            dense128_s16_plain(ring, lane, g, x, hid);
+            dense128_s16_plain<kDma>(ring, lane, g, x, hid);
+            if (kStash && tile_ok) store_tl16(p.stash_fused + (1 + 2 * (bi - 3)) * p.stash_fused_stride, tile, n, g, hid);
             bias16<true>(bias1 + 128, g, x);
-            dense128_s16_plain(ring, lane, g, hid, x);
+            dense128_s16_plain<kDma>(ring, lane, g, hid, x);
+            if (kStash && tile_ok) store_tl16(p.stash_fused + (2 + 2 * (bi - 3)) * p.stash_fused_stride, tile, n, g, x);
 #endif
             if (kAux && p.acts_fused) store_fused16(p.acts_fused + (long)(bi - 2) * p.total * 128);
         }
@@ -851,7 +876,8 @@ hipError_t launch_pack_net_split16(const float* net_keras, void* packed_split16,
 }
 
 bool field_eval_split16_supports(const FieldParams& p) {
-    if (p.stash || p.stash_fused) return false;                              // training forward: field_eval_split_kernel
+    if (p.stash && MVS16_TAIL) return false;                                 // the stash stores are built into the plain layer flow only
+    if (p.stash && (p.tap_idx || p.pix || p.embedding || p.acts_view || p.acts_fused)) return false;
     const int n_pos = ((p.texel_table ? kS16L0Pe : kS16L0Pe + kS16L0Feat) + kS16PerView) * p.V + kS16PerView;
     return n_pos <= kS16MaxPositions;
 }
@@ -872,14 +898,18 @@ hipError_t launch_field_eval_split16(const FieldParams& p, const void* packed_sp
             hipDeviceProp_t prop;
             if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
             cus[dev] = prop.multiProcessorCount;
-            const void* fns[8] = {reinterpret_cast<const void*>(&field_eval_split16_kernel<false, false, false>),
-                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<false, true, false>),
-                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<true, false, false>),
-                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<true, true, false>),
-                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<false, false, true>),
-                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<false, true, true>),
-                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<true, false, true>),
-                                  reinterpret_cast<const void*>(&field_eval_split16_kernel<true, true, true>)};
+            const void* fns[12] = {reinterpret_cast<const void*>(&field_eval_split16_kernel<false, false, false, false>),
+                                   reinterpret_cast<const void*>(&field_eval_split16_kernel<false, true, false, false>),
+                                   reinterpret_cast<const void*>(&field_eval_split16_kernel<true, false, false, false>),
+                                   reinterpret_cast<const void*>(&field_eval_split16_kernel<true, true, false, false>),
+                                   reinterpret_cast<const void*>(&field_eval_split16_kernel<false, false, true, false>),
+                                   reinterpret_cast<const void*>(&field_eval_split16_kernel<false, true, true, false>),
+                                   reinterpret_cast<const void*>(&field_eval_split16_kernel<true, false, true, false>),
+                                   reinterpret_cast<const void*>(&field_eval_split16_kernel<true, true, true, false>),
+                                   reinterpret_cast<const void*>(&field_eval_split16_kernel<false, false, false, true>),
+                                   reinterpret_cast<const void*>(&field_eval_split16_kernel<false, true, false, true>),
+                                   reinterpret_cast<const void*>(&field_eval_split16_kernel<true, false, false, true>),
+                                   reinterpret_cast<const void*>(&field_eval_split16_kernel<true, true, false, true>)};
             for (const void* fn : fns)
                 if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess) return e;
             attr_done[dev] = true;
@@ -892,18 +922,29 @@ hipError_t launch_field_eval_split16(const FieldParams& p, const void* packed_sp
     const unsigned wgs = (unsigned)(n_groups < resident ? n_groups : resident);
     const f32x4* w = static_cast<const f32x4*>(packed_split16);
     const dim3 grid(wgs), block(512);
-#define MVS16_LAUNCH(MV, PROJ, AUX) hipLaunchKernelGGL((field_eval_split16_kernel<MV, PROJ, AUX>), grid, block, lds_bytes, stream, p, w)
+#define MVS16_LAUNCH(MV, PROJ, AUX, STASH) hipLaunchKernelGGL((field_eval_split16_kernel<MV, PROJ, AUX, STASH>), grid, block, lds_bytes, stream, p, w)
     const bool aux = p.tap_idx || p.pix || p.embedding || p.acts_view || p.acts_fused;
+    if (p.stash && p.V > 1 && ((long)p.R * p.S) % 32 != 0) return hipErrorInvalidValue;     // tiles must not straddle scenes
+    if (p.stash) {
+        const int variant = (mv ? 2 : 0) + (p.texel_table ? 1 : 0);
+        switch (variant) {
+            case 0: MVS16_LAUNCH(false, false, false, true); break;
+            case 1: MVS16_LAUNCH(false, true, false, true); break;
+            case 2: MVS16_LAUNCH(true, false, false, true); break;
+            default: MVS16_LAUNCH(true, true, false, true); break;
+        }
+        return hipGetLastError();
+    }
     const int variant = (mv ? 4 : 0) + (p.texel_table ? 2 : 0) + (aux ? 1 : 0);
     switch (variant) {
-        case 0: MVS16_LAUNCH(false, false, false); break;
-        case 1: MVS16_LAUNCH(false, false, true); break;
-        case 2: MVS16_LAUNCH(false, true, false); break;
-        case 3: MVS16_LAUNCH(false, true, true); break;
-        case 4: MVS16_LAUNCH(true, false, false); break;
-        case 5: MVS16_LAUNCH(true, false, true); break;
-        case 6: MVS16_LAUNCH(true, true, false); break;
-        default: MVS16_LAUNCH(true, true, true); break;
+        case 0: MVS16_LAUNCH(false, false, false, false); break;
+        case 1: MVS16_LAUNCH(false, false, true, false); break;
+        case 2: MVS16_LAUNCH(false, true, false, false); break;
+        case 3: MVS16_LAUNCH(false, true, true, false); break;
+        case 4: MVS16_LAUNCH(true, false, false, false); break;
+        case 5: MVS16_LAUNCH(true, false, true, false); break;
+        case 6: MVS16_LAUNCH(true, true, false, false); break;
+        default: MVS16_LAUNCH(true, true, true, false); break;
     }
 #undef MVS16_LAUNCH
     return hipGetLastError();
