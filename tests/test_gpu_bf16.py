@@ -183,3 +183,50 @@ def test_bf16_feature_maps_give_the_same_bits_as_fp32_maps_holding_the_same_valu
     o32 = m.infer(inputs, maps32, u_coarse=d['u_coarse'], u_fine=d['u_fine'])
     for x, y in zip(o16, o32):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('views,n_rays,s', [(1, 40, 64), (3, 17, 128), (2, 3000, 64)])
+def test_bf16_layer_ring_kernel_agrees_with_the_segment_ring_kernel(views, n_rays, s, monkeypatch):
+    """The texel-table form of the bf16 field pass runs on field_eval_bf16x.hip (16x16x32 MFMA, one ring slot per layer);
+    MVNERF_BF16_KERNEL=segments pins the round-2 kernel (field_eval_bf16.hip) for the same call.  Both round the same values to
+    bf16 at the same places (layer-0 inputs, relu(x) / relu(hid) per Dense) and accumulate in fp32, so their activations differ by
+    summation order and by samples whose value sits on a bf16 rounding boundary; the read-out differs by design (fp32 here)."""
+    sc = make_scene(seed=80 + views, n_views=views, height=24, width=24, n_rays=n_rays, bias_scale=0.1)
+    d = {k: dev(sc[k]) for k in ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'fine']}
+    rng = np.random.default_rng(1)
+    z = dev(np.sort(rng.uniform(0.3, 1.3, (1, n_rays, s)).astype(np.float32), -1))
+    packed, packed16 = ops.pack_net(d['fine']), ops.pack_net_bf16(d['fine'])
+    table = ops.project_texels(d['features'], packed)
+    args = (d['rays_o'], d['rays_d'], z, d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'], packed, packed16)
+    kw = dict(return_taps=True, return_embedding=True, return_fused_acts=True, texel_table=table)
+    monkeypatch.setenv('MVNERF_BF16_KERNEL', 'layers')                         # V > 1 too (the default sends only V = 1 to the new kernel)
+    new = ops.field_eval_bf16(*args, **kw)
+    plain = ops.field_eval_bf16(*args, texel_table=table)                      # the variant without the auxiliary outputs
+    monkeypatch.setenv('MVNERF_BF16_KERNEL', 'segments')
+    old = ops.field_eval_bf16(*args, **kw)
+    monkeypatch.setenv('MVNERF_BF16_KERNEL', 'layers')
+    again = ops.field_eval_bf16(*args, **kw)
+    monkeypatch.delenv('MVNERF_BF16_KERNEL')
+    default = ops.field_eval_bf16(*args, **kw)
+    assert torch.equal(default[0], new[0] if views == 1 else old[0])
+    ref = ops.field_eval(*args[:8], texel_table=table)
+    torch.cuda.synchronize()
+    assert torch.equal(new[1], old[1])                                         # tap indices
+    assert torch.equal(new[0], plain)
+    for a, b in zip(new, again):
+        assert torch.equal(a, b)                                               # deterministic
+    assert not torch.equal(new[0], old[0])                                     # really two kernels
+    for k in range(4):
+        scale = old[3][k].abs().mean().item()
+        dk = (new[3][k] - old[3][k]).abs().mean().item()
+        print(f'bf16 V={views}: fused act {k}: layer-ring vs segment-ring mean |d| {dk:.2e} of mean |a| {scale:.2e}')
+        assert dk < 2e-3 * scale
+    assert torch.equal(new[3][3], new[2])
+    # the read-out: this kernel keeps Dense 128 -> 4 in fp32 on the vector ALU (the segment kernel rounds relu(emb) and Wr to bf16),
+    # so its outputs are the fp32 oracle's read-out of its own embedding
+    rgb_o, sig_o = O.render_readout(O.unflatten_net(sc['fine']), new[2].cpu().numpy())
+    got = new[0].cpu().numpy()
+    assert np.abs(got[..., :3] - rgb_o).max() < 2e-6 and np.abs(got[..., 3] - sig_o).max() < 1e-5 * max(1.0, float(sig_o.max()))
+    e_new, e_old = (new[0] - ref).abs().mean().item(), (old[0] - ref).abs().mean().item()
+    print(f'bf16 V={views}: layer-ring vs segment-ring mean |d| {(new[0] - old[0]).abs().mean().item():.2e}; vs fp32 kernel {e_new:.2e} / {e_old:.2e}')
+    assert e_new < 1.05 * e_old + 1e-6 and (new[0] - ref).abs().max().item() < 5e-2

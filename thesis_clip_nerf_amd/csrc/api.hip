@@ -172,7 +172,7 @@ int mvnerf_field_eval_table(const float* rays_o, const float* rays_d, const floa
                            S, H, W, rgbs, tap_idx, pix, embedding, acts_per_view, acts_fused, workspace, stream);
 }
 
-size_t mvnerf_packed_net_bf16_bytes(void) { return (size_t)480 * 1024; }
+size_t mvnerf_packed_net_bf16_bytes(void) { return mvnerf::packed_net_bf16_bytes(); }
 
 int mvnerf_pack_net_bf16(const float* net_keras, void* packed16, mvnerf_stream_t stream) {
     if (!net_keras || !packed16) return fail(MVNERF_E_ARG, "mvnerf_pack_net_bf16: null pointer");

@@ -16,6 +16,8 @@
 //  * the per-(view, ray) layer-0 seed (b0 + W0_dir^T PE(dir)) is the fp32 one of dir_bias_kernel.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <mutex>
 
 #include "mvnerf_kernels.h"
@@ -69,10 +71,20 @@ __global__ void pack_net_bf16_kernel(const float* __restrict__ src, __bf16* __re
     dst[idx] = (__bf16)val;
 }
 
+size_t packed_net_bf16_bytes() { return (size_t)kW16Chunks * 1024 + packed_net_bf16x_bytes(); }
+
 hipError_t launch_pack_net_bf16(const float* net_keras, void* packed16, hipStream_t st) {
     const int n = kW16Chunks * kW16ChunkElems;
     hipLaunchKernelGGL(pack_net_bf16_kernel, dim3((n + 255) / 256), dim3(256), 0, st, net_keras, static_cast<__bf16*>(packed16));
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_pack_net_bf16x(net_keras, static_cast<unsigned char*>(packed16) + (size_t)kW16Chunks * 1024, st);
+}
+
+// MVNERF_BF16_KERNEL=segments pins the round-2 segment-ring kernel for the texel-table form too (A/B runs, tests of both kernels)
+static bool bf16x_enabled() {
+    const char* e = getenv("MVNERF_BF16_KERNEL");                        // read per launch: a test flips it inside one process
+    return !(e && e[0] == 's');
 }
 
 // ---- the segment ring ----------------------------------------------------------------------------------------
@@ -708,6 +720,8 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void field_eval_bf16_kernel(Field
 }
 
 hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hipStream_t stream, bool maps_bf16) {
+    if (bf16x_enabled() && field_eval_bf16x_supports(p))
+        return launch_field_eval_bf16x(p, static_cast<const unsigned char*>(packed16) + (size_t)kW16Chunks * 1024, stream);
     static std::mutex mtx;
     static bool attr_done[16] = {};
     static int cus[16] = {};

@@ -48,7 +48,13 @@ hipError_t launch_dir_bias(const FieldParams& p, hipStream_t stream);
 hipError_t launch_project_texels(const float* features, const float* packed_net, const float* packed_net1, long n_texels,
                                  float* table, float* table1, hipStream_t stream);
 hipError_t launch_field_jvp(const FieldParams& p, hipStream_t stream);
-hipError_t launch_pack_net_bf16(const float* net_keras, void* packed16, hipStream_t st);
+size_t packed_net_bf16_bytes();          // the field_eval_bf16.hip stream (480 KiB) followed by the field_eval_bf16x.hip stream
+hipError_t launch_pack_net_bf16(const float* net_keras, void* packed16, hipStream_t st);   // packs both
+// field_eval_bf16x.hip: the texel-table form of the bf16 field pass on v_mfma_f32_16x16x32_bf16, one ring slot per layer
+size_t packed_net_bf16x_bytes();
+hipError_t launch_pack_net_bf16x(const float* net_keras, void* packed16x, hipStream_t st);
+bool field_eval_bf16x_supports(const FieldParams& p);
+hipError_t launch_field_eval_bf16x(const FieldParams& p, const void* packed16x, hipStream_t stream);
 hipError_t launch_project_texels_bf16(const float* features, const void* packed16, const void* packed16b, long n_texels, float* table,
                                       float* table1, hipStream_t stream);
 hipError_t launch_field_eval_bf16(const FieldParams& p, const void* packed16, hipStream_t stream, bool maps_bf16 = false);   // maps_bf16: p.features holds bf16
