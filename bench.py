@@ -64,6 +64,9 @@ def mfma_per_tile(v, table, bf16=False, split=False):
         return 96 * (v * ((2 if table else 10) + 24) + 24)
     if split:      # field_eval_split.hip: per k-step of 16 rows 4 output blocks x 6 products; PE(dir) in the per-ray seed
         return 24 * (v * ((4 if table else 20) + 48) + 48) + 48
+    if bf16 == 'x':  # field_eval_bf16x.hip (texel-table form at V = 1): v_mfma_f32_16x16x32_bf16, 8 row blocks x 2 column blocks per t-step of K = 32;
+        #              layer 0: 2 t-steps (PE(cam xyz) + rgb), 12 hidden layers x 4 t-steps; read-out on the vector ALU in fp32
+        return 16 * (v * (2 + 24) + 24)
     if bf16:       # field_eval_bf16.hip: K = 16 per MFMA; direct form streams PE(xyz) 64 + PE(dir) 64 + 256 feature rows, the table
         #            form 64 rows (PE(dir) in the per-ray seed, features from the table); read-out = 2 k-steps x 4 blocks on the MFMA
         l0 = (64 if table else 384) // 16 * 4
@@ -253,16 +256,18 @@ def main():
         n_tiles_c, n_tiles_f = (b * r * s + 31) // 32, (b * r * 2 * s + 31) // 32
         # which split kernel runs the inference passes: field_eval_split16_kernel unless MVNERF_SPLIT_MFMA=32x32x16 pins the round-2 kernel
         split_shape = (32 if os.environ.get('MVNERF_SPLIT_MFMA', '').startswith('3') else 16) if split else False
-        mpt = mfma_per_tile(args.views, use_table, bf16, split_shape)
-        fpm = flop_per_mfma(bf16 or bool(split), split_shape)
+        # bf16: the layer-ring kernel (field_eval_bf16x.hip) runs the texel-table form at V = 1 unless MVNERF_BF16_KERNEL=segments pins round 2's
+        bf16x = bf16 and use_table and args.views == 1 and not os.environ.get('MVNERF_BF16_KERNEL', '').startswith('s')
+        mpt = mfma_per_tile(args.views, use_table, 'x' if bf16x else bf16, split_shape)
+        fpm = flop_per_mfma(bf16 or bool(split), 16 if bf16x else split_shape)
         flops_c, flops_f = n_tiles_c * mpt * fpm, n_tiles_f * mpt * fpm
         fps_ref = reference_flop_per_sample(args.views)
         # the fine-pass launch is the dominant kernel instance (2/3 of the FLOPs)
         achieved = flops_f / (fine_ms * 1e-3) / 1e12
         peak = 2500.0 if (bf16 or split) else PEAK_FP32_MFMA_TFLOPS   # dense bf16 MFMA peak ~2.5 PFLOP/s
-        kname = (('field_eval_bf16_kernel' if bf16 else ('field_eval_split16_kernel' if split_shape == 16 else 'field_eval_split_kernel') if split else 'field_eval_kernel') +
+        kname = ((('field_eval_bf16x_kernel' if bf16x else 'field_eval_bf16_kernel') if bf16 else ('field_eval_split16_kernel' if split_shape == 16 else 'field_eval_split_kernel') if split else 'field_eval_kernel') +
                  ('<true' if args.views > 1 else '<false') +
-                 ((',true>' if use_table else ',false>') if (bf16 or split_shape == 16) else (',true,false>' if use_table else ',false,false>') if split else
+                 ((',false>' if bf16x else ',true>' if use_table else ',false>') if (bf16 or split_shape == 16) else (',true,false>' if use_table else ',false,false>') if split else
                   (',false,true>' if use_table else ',false,false>')))
         ref_tflops = fps_ref * b * r * 2 * s / (fine_ms * 1e-3) / 1e12
         peak_dtype = 'bf16' if (bf16 or split) else 'f32'
