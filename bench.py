@@ -20,12 +20,14 @@ scene (rays/scenes are independent units, no data-path collective) -> weak scali
 16 384 x K / time and `scaling` reads "strong".  The default (and what the driver runs) is the weak leg above.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the fine-pass launch of the field kernel.  Default
-(`--f32-gemm split_bf16`): `field_eval_split_kernel` - fp32 operands cut exactly into three bf16 pieces, six
-v_mfma_f32_32x32x16_bf16 per product block, fp32 accumulation - so the pipe it is bound by is the bf16 matrix pipe:
-`peak` = 2 500 TFLOP/s dense bf16 (`peak_dtype`), `achieved` / `frac` = `frac_executed` count the FLOPs the launch EXECUTES there
-(tiles x MFMAs per 32-sample tile x 32 768 FLOP per MFMA; the count is checked against SQ_INSTS_MFMA in profiles/), and
+(`--f32-gemm split_f16`): `field_eval_split16h_kernel` - every fp32 operand as two fp16 pieces (round-to-nearest twice: 22-24
+significant bits), three v_mfma_f32_16x16x32_f16 per product block, fp32 accumulation; fp32-grade (per ResNet block as close to a
+float64 evaluation as the fp32 MFMA kernel, tests/test_gpu_split.py) - so the pipe it is bound by is the 16-bit matrix pipe:
+`peak` = 2 500 TFLOP/s dense fp16 / bf16 (`peak_dtype`), `achieved` / `frac` = `frac_executed` count the FLOPs the launch EXECUTES
+there (tiles x MFMAs per 32-sample tile x 16 384 FLOP per MFMA; the count is checked against SQ_INSTS_MFMA in profiles/), and
 `frac_algorithmic` restates the same duration in SURVEY.md 8d's algorithmic figure (491 264 FLOP per sample at V = 1) against the
-same peak - 5.1x lower, the price of fp32-grade products on a bf16 pipe.  `--f32-gemm mfma_f32` times `field_eval_kernel` on the
+same peak - 2.6x lower, the price of fp32-grade products on a 16-bit pipe.  `--f32-gemm split_bf16` times `field_eval_split16_kernel`
+(exact three-piece bf16 cut, six v_mfma_f32_16x16x32_bf16 per block: round 3's first default).  `--f32-gemm mfma_f32` times `field_eval_kernel` on the
 fp32 MFMA (v_mfma_f32_32x32x2_f32, 4 096 FLOP each, peak 157.3 TFLOP/s).  Durations are HIP events inside the timed region;
 `traffic` / `traffic_ratio` / `mfma_busy_pmc` come from the committed rocprofv3 counter passes (`traffic_source`).
 `cpu_baseline` times the op-for-op torch-CPU restatement of the reference's TF graph (oracle/mvnerf_torch.py, fp32; the reference
@@ -58,10 +60,12 @@ def mfma_per_tile(v, table, bf16=False, split=False):
     padded; the 60 PE(cam dir) rows are a per-ray seed computed on the vector ALU) + 256 feature rows unless those come from
     the texel table; 12 hidden layers of K = 128; the 128->4 read-out runs on the vector ALU.  One k-step covers K = 2 (fp32
     32x32x2) for each of the 4 output blocks of 32 features."""
-    if split == 16:  # field_eval_split16.hip (default inference kernel): k-steps of K = 32 rows x 8 row blocks x 2 column blocks x 6 products of
-        #              v_mfma_f32_16x16x32_bf16 (16 384 FLOP each); layer 0: 2 k-steps (+ 8 for the feature rows without the texel table);
-        #              6 Dense layers x 4 k-steps per view, 6 x 4 fused; the read-out on the vector ALU
-        return 96 * (v * ((2 if table else 10) + 24) + 24)
+    if split in (16, '16h'):
+        # field_eval_split16[h].hip: k-steps of K = 32 rows x 8 row blocks x 2 column blocks x 6 products of v_mfma_f32_16x16x32_bf16
+        # (three bf16 pieces per operand) or 3 products of v_mfma_f32_16x16x32_f16 (two fp16 pieces: the default), 16 384 FLOP each;
+        # layer 0: 2 k-steps (+ 8 for the feature rows without the texel table); 6 Dense layers x 4 k-steps per view, 6 x 4 fused;
+        # the read-out on the vector ALU
+        return (48 if split == '16h' else 96) * (v * ((2 if table else 10) + 24) + 24)
     if split:      # field_eval_split.hip: per k-step of 16 rows 4 output blocks x 6 products; PE(dir) in the per-ray seed
         return 24 * (v * ((4 if table else 20) + 48) + 48) + 48
     if bf16 == 'x':  # field_eval_bf16x.hip (texel-table form at V = 1): v_mfma_f32_16x16x32_bf16, 8 row blocks x 2 column blocks per t-step of K = 32;
@@ -77,7 +81,7 @@ def mfma_per_tile(v, table, bf16=False, split=False):
 
 
 def flop_per_mfma(bf16=False, split=False):
-    if split == 16:
+    if split in (16, '16h'):
         return 2 * 16 * 16 * 32
     return 2 * 32 * 32 * (16 if bf16 else 2)
 
@@ -117,8 +121,8 @@ def main():
     ap.add_argument('--rays', type=int, default=0, help='random target pixels instead of every pixel of a size x size view (e.g. cfg5: 16384 rays, 480x640 sources)')
     ap.add_argument('--cpu-baseline', default='on', choices=['on', 'off'], help='N=1: time the torch-CPU restatement and check parity on all rays')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='bf16: both field passes on the bf16 MFMA kernel (configs 3/5; not the headline)')
-    ap.add_argument('--f32-gemm', default='split_bf16', choices=['mfma_f32', 'split_bf16'],
-                    help='fp32 Dense layers on the fp32 MFMA, or as six bf16 MFMAs per product on exactly split operands (fp32-grade, csrc/field_eval_split.hip)')
+    ap.add_argument('--f32-gemm', default='split_f16', choices=['mfma_f32', 'split_bf16', 'split_f16'],
+                    help='fp32 Dense layers on the fp32 MFMA, or fp32-grade on the 16-bit matrix pipe: three fp16 MFMAs per product block on two-piece operands (default) or six bf16 MFMAs on exactly cut three-piece operands')
     ap.add_argument('--texel-table', default='auto', choices=['auto', 'on', 'off'],
                     help="hoist layer 0's feature rows to a per-texel table rebuilt every step (auto: when R*S >= 2*H*W)")
     ap.add_argument('--train-steps', type=int, default=5,
@@ -175,7 +179,9 @@ def main():
          ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'u_coarse', 'u_fine', 'coarse', 'fine']}
     pc, pf = ops.pack_net(t['coarse']), ops.pack_net(t['fine'])
     bf16 = args.dtype == 'bf16'
-    split = args.f32_gemm == 'split_bf16' and not bf16
+    split = args.f32_gemm != 'mfma_f32' and not bf16
+    if split:
+        ops.set_split_kernel(args.f32_gemm)
     if bf16:
         pc16, pf16 = ops.pack_net_bf16(t['coarse']), ops.pack_net_bf16(t['fine'])
     if split:
@@ -254,8 +260,10 @@ def main():
         coarse_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         fine_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
         n_tiles_c, n_tiles_f = (b * r * s + 31) // 32, (b * r * 2 * s + 31) // 32
-        # which split kernel runs the inference passes: field_eval_split16_kernel unless MVNERF_SPLIT_MFMA=32x32x16 pins the round-2 kernel
-        split_shape = (32 if os.environ.get('MVNERF_SPLIT_MFMA', '').startswith('3') else 16) if split else False
+        # which split kernel runs the inference passes (csrc/field_eval_split.hip, split_kernel_choice): field_eval_split16h_kernel (two fp16
+        # pieces, three products) unless MVNERF_SPLIT_MFMA pins field_eval_split16_kernel ("bf16x6") or round 2's kernel ("32x32x16")
+        env_split = os.environ.get('MVNERF_SPLIT_MFMA', '') or {'split_f16': 'f16x3', 'split_bf16': 'bf16x6'}.get(args.f32_gemm, '')
+        split_shape = (32 if env_split.startswith('3') else 16 if env_split.startswith('b') else '16h') if split else False
         # bf16: the layer-ring kernel (field_eval_bf16x.hip) runs the texel-table form at V = 1 unless MVNERF_BF16_KERNEL=segments pins round 2's
         bf16x = bf16 and use_table and args.views == 1 and not os.environ.get('MVNERF_BF16_KERNEL', '').startswith('s')
         mpt = mfma_per_tile(args.views, use_table, 'x' if bf16x else bf16, split_shape)
@@ -265,12 +273,12 @@ def main():
         # the fine-pass launch is the dominant kernel instance (2/3 of the FLOPs)
         achieved = flops_f / (fine_ms * 1e-3) / 1e12
         peak = 2500.0 if (bf16 or split) else PEAK_FP32_MFMA_TFLOPS   # dense bf16 MFMA peak ~2.5 PFLOP/s
-        kname = ((('field_eval_bf16x_kernel' if bf16x else 'field_eval_bf16_kernel') if bf16 else ('field_eval_split16_kernel' if split_shape == 16 else 'field_eval_split_kernel') if split else 'field_eval_kernel') +
+        kname = ((('field_eval_bf16x_kernel' if bf16x else 'field_eval_bf16_kernel') if bf16 else ('field_eval_split16h_kernel' if split_shape == '16h' else 'field_eval_split16_kernel' if split_shape == 16 else 'field_eval_split_kernel') if split else 'field_eval_kernel') +
                  ('<true' if args.views > 1 else '<false') +
-                 ((',false>' if bf16x else ',true>' if use_table else ',false>') if (bf16 or split_shape == 16) else (',true,false>' if use_table else ',false,false>') if split else
+                 ((',false>' if bf16x else ',true>' if use_table else ',false>') if bf16 else (',true,false,false>' if use_table else ',false,false,false>') if split_shape in (16, '16h') else (',true,false>' if use_table else ',false,false>') if split else
                   (',false,true>' if use_table else ',false,false>')))
         ref_tflops = fps_ref * b * r * 2 * s / (fine_ms * 1e-3) / 1e12
-        peak_dtype = 'bf16' if (bf16 or split) else 'f32'
+        peak_dtype = ('f16' if split_shape == '16h' else 'bf16') if (bf16 or split) else 'f32'
         result['roofline'] = {
             'bound': 'mfma', 'kernel': kname + ' (fine pass, S=128)',
             'achieved': achieved, 'peak': peak, 'peak_dtype': peak_dtype, 'unit': 'TFLOP/s', 'frac': achieved / peak,
@@ -299,15 +307,18 @@ def main():
             # the matrix-pipe utilisation (executed bf16 FLOPs / 2.5 PFLOP/s); this is the same launch measured in the
             # reference graph's fp32 FLOPs against the fp32 MFMA peak the round-1 kernel was bound by
             result['roofline']['reference_equiv_vs_fp32_mfma_peak'] = ref_tflops / PEAK_FP32_MFMA_TFLOPS
-            result['roofline']['arithmetic'] = ('fp32 operands cut exactly into 3 bf16 pieces, 6 ' +
-                                                ('v_mfma_f32_16x16x32_bf16' if split_shape == 16 else 'v_mfma_f32_32x32x16_bf16') +
-                                                ' per product block, fp32 accumulate (dropped terms <= 2^-24 relative)')
+            result['roofline']['arithmetic'] = (
+                'fp32 operands as two fp16 pieces (round-to-nearest twice, the remainder scaled by 64: 22-24 significant bits), 3 v_mfma_f32_16x16x32_f16 '
+                'per product block, fp32 accumulate; per ResNet block as close to a float64 evaluation as the fp32 MFMA kernel '
+                '(tests/test_gpu_split.py::test_products_of_the_three_fp32_grade_kernels_against_float64)' if split_shape == '16h' else
+                'fp32 operands cut exactly into 3 bf16 pieces, 6 ' + ('v_mfma_f32_16x16x32_bf16' if split_shape == 16 else 'v_mfma_f32_32x32x16_bf16') +
+                ' per product block, fp32 accumulate (dropped terms <= 2^-24 relative)')
         if use_table:
             result['roofline']['project_texels_ms_per_step'] = float(np.mean([e[4].elapsed_time(e[5]) for e in ev]))
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc) and not bf16 and (use_table or not split) and args.views == 1 and (img_h, img_w, r) == (64, 64, 4096):   # counters were collected on cfg2
             try:
-                key = ('field_eval_split16_table_fine_hbm_bytes_per_launch' if split_shape == 16 else
+                key = ('field_eval_split16h_table_fine_hbm_bytes_per_launch' if split_shape == '16h' else 'field_eval_split16_table_fine_hbm_bytes_per_launch' if split_shape == 16 else
                        'field_eval_split_table_fine_hbm_bytes_per_launch' if split else
                        'field_eval_table_fine_hbm_bytes_per_launch' if use_table else 'field_eval_fine_hbm_bytes_per_launch')
                 counters = json.load(open(pmc))
@@ -317,7 +328,7 @@ def main():
                     alg = counters.get('algorithmic_bytes_per_launch')
                     rl['traffic_algorithmic_bytes'] = alg
                     rl['traffic_ratio'] = counters[key] / alg if alg else None
-                    rl['traffic_source'] = 'profiles/pmc_traffic.json <- ' + str(counters.get('source_split16' if split_shape == 16 else 'source_split' if split else 'source_table' if use_table else 'source'))[:200]
+                    rl['traffic_source'] = 'profiles/pmc_traffic.json <- ' + str(counters.get('source_split16h' if split_shape == '16h' else 'source_split16' if split_shape == 16 else 'source_split' if split else 'source_table' if use_table else 'source'))[:200]
                     rl['traffic_note'] = ('HBM-side bytes (FETCH_SIZE x2 + WRITE_SIZE) exceed the algorithmic bytes because each of the 8 XCD L2s pulls '
                                           'its own copy of the texel table and the weight stream, and because of the kernel\'s remaining register spills '
                                           '(scratch); at the rate below that is about 1 % of the 8 TB/s HBM peak')

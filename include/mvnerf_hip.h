@@ -151,12 +151,27 @@ int mvnerf_field_eval_bf16maps(const float* rays_o, const float* rays_d, const f
                                float* rgbs, int32_t* tap_idx, float* embedding, float* acts_fused, void* workspace,
                                mvnerf_stream_t stream);
 
-/* ---- fp32-grade field pass on the bf16 matrix pipe ("split3"): every fp32 GEMM operand is cut exactly into three
- * bf16 pieces and a product is issued as the six bf16 MFMAs of order >= 2^-16 with fp32 accumulation; the dropped terms
- * are <= 2^-24 relative, one fp32 rounding (csrc/field_eval_split.hip).  Same function, inputs, outputs and 1e-4 bar as
- * mvnerf_field_eval / mvnerf_field_eval_table (model_v0.py:122-144 / :157-180) at 6/16 of the fp32 MFMA's matrix time. ---- */
+/* ---- fp32-grade field pass on the 16-bit matrix pipe ("split"): every fp32 GEMM operand is represented by 16-bit pieces and a
+ * product block is issued as a few 16-bit MFMAs with fp32 accumulation.  Same function, inputs, outputs and 1e-4 bar as
+ * mvnerf_field_eval / mvnerf_field_eval_table (model_v0.py:122-144 / :157-180).  Three kernels read the same packed_split image
+ * (mvnerf_set_split_kernel):
+ *   MVNERF_SPLIT_F16X3 (default)  two fp16 pieces per operand (round-to-nearest twice, the remainder scaled by 64: 22-24 significant
+ *                                 bits), three v_mfma_f32_16x16x32_f16 per block; per ResNet block as close to a float64 evaluation as
+ *                                 the fp32 MFMA (tests/test_gpu_split.py); range |w| < 4094, |activation| < 1.04e6
+ *                                 (csrc/field_eval_split16_impl.h, field_eval_split16h.hip); inference only
+ *   MVNERF_SPLIT_BF16X6           three bf16 pieces per operand, an EXACT cut, the six products of order >= 2^-16 as
+ *                                 v_mfma_f32_16x16x32_bf16; dropped terms <= 2^-24 relative; full fp32 range (field_eval_split16.hip)
+ *   MVNERF_SPLIT_BF16X6_32        the same products as v_mfma_f32_32x32x16_bf16 (round 2's kernel, field_eval_split.hip)
+ * The training forward (mvnerf_field_eval_stash_split) always uses an exact-cut kernel. ---- */
+#define MVNERF_SPLIT_F16X3 0
+#define MVNERF_SPLIT_BF16X6 1
+#define MVNERF_SPLIT_BF16X6_32 2
+/* Process-wide choice of the kernel behind mvnerf_field_eval_split / mvnerf_render_fwd_split; returns the previous value (< 0 and
+ * no change for an unknown value).  The environment variable MVNERF_SPLIT_MFMA ("f16x3" | "bf16x6" | "32x32x16"), read at every
+ * launch, overrides it (A/B runs, tests). */
+int mvnerf_set_split_kernel(int which);
 size_t mvnerf_packed_net_split_bytes(void);
-/* Keras-order fp32 MLP (see mvnerf_pack_net) -> three-piece bf16 operand stream.  packed_split: 16-byte aligned. */
+/* Keras-order fp32 MLP (see mvnerf_pack_net) -> the operand streams of the three kernels above.  packed_split: 16-byte aligned. */
 int mvnerf_pack_net_split(const float* net_keras, void* packed_split, mvnerf_stream_t stream);
 /* As mvnerf_field_eval (texel_table NULL) / mvnerf_field_eval_table, with the Dense kernels taken from packed_split
  * (biases, the per-ray layer-0 seed and the texel table still come from the fp32 image packed_net).  Optional outputs

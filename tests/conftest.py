@@ -28,3 +28,11 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+@pytest.fixture(autouse=True)
+def _default_split_kernel():
+    """mvnerf_set_split_kernel is process-wide state: every test starts from the default (two fp16 pieces, three products)."""
+    yield
+    from thesis_clip_nerf_amd import ops
+    ops.set_split_kernel('split_f16')

@@ -62,14 +62,22 @@ def cfg5():
     del sc['features']
 
 
-GEMMS = ['split_bf16', 'mfma_f32']      # the two fp32 field kernels (MVVNeRFRenderer(f32_gemm=...)); the default, which bench.py times, first
+GEMMS = ['split_f16', 'split_bf16', 'mfma_f32']      # the three fp32 field kernels (MVVNeRFRenderer(f32_gemm=...)); the default, which bench.py times, first
 
 
-def _render(d, sl=slice(None), tables='auto', gemm='split_bf16'):
+def _split(d, gemm):
+    """The packed split image for the two split kernels (selecting which of them runs), None for the fp32-MFMA kernel."""
+    if gemm == 'mfma_f32':
+        return None
+    ops.set_split_kernel(gemm)
+    return d['split']
+
+
+def _render(d, sl=slice(None), tables='auto', gemm='split_f16'):
     pick = lambda t: t[:, sl].contiguous()
     return ops.render_fwd(pick(d['rays_o']), pick(d['rays_d']), d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'],
                           d['pc'], d['pf'], pick(d['u_coarse']), pick(d['u_fine']), d['near'], d['far'], texel_tables=tables,
-                          split=d['split'] if gemm == 'split_bf16' else None)
+                          split=_split(d, gemm))
 
 
 @pytest.mark.parametrize('gemm', GEMMS)
@@ -107,7 +115,7 @@ def test_cfg5_tap_indices_and_sample_indices_bit_exact(cfg5, gemm):
     z = ops.stratified_depths(d['u_coarse'], d['near'], d['far'])
     np.testing.assert_array_equal(z[:, sub_t].cpu().numpy(), aux['z'])      # fp32, identical bits
     geo = (d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'])
-    if gemm == 'split_bf16':
+    if _split(d, gemm) is not None:
         rgbs_c, taps_c = ops.field_eval_split(d['rays_o'], d['rays_d'], z, *geo, d['pc'], d['split'][0], return_taps=True)
     else:
         rgbs_c, taps_c = ops.field_eval(d['rays_o'], d['rays_d'], z, *geo, d['pc'], return_taps=True)

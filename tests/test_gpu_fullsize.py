@@ -31,14 +31,22 @@ def scene(request):
     return d
 
 
-GEMMS = ['split_bf16', 'mfma_f32']                                          # MVVNeRFRenderer(f32_gemm=...): default first
+GEMMS = ['split_f16', 'split_bf16', 'mfma_f32']                             # MVVNeRFRenderer(f32_gemm=...): default (what bench.py times) first
 
 
-def render(d, sl=slice(None), tables='auto', perm=None, gemm='split_bf16'):
+def _split(d, gemm):
+    """The packed split image for the two split kernels (selecting which of them runs), None for the fp32-MFMA kernel."""
+    if gemm == 'mfma_f32':
+        return None
+    ops.set_split_kernel(gemm)
+    return d['split']
+
+
+def render(d, sl=slice(None), tables='auto', perm=None, gemm='split_f16'):
     pick = (lambda t: t[:, sl]) if perm is None else (lambda t: t[:, perm])
     return ops.render_fwd(pick(d['rays_o']).contiguous(), pick(d['rays_d']).contiguous(), d['images'], d['features'], d['intrinsics'],
                           d['extrinsics_inv'], d['pc'], d['pf'], pick(d['u_coarse']).contiguous(), pick(d['u_fine']).contiguous(),
-                          d['near'], d['far'], texel_tables=tables, split=d['split'] if gemm == 'split_bf16' else None)
+                          d['near'], d['far'], texel_tables=tables, split=_split(d, gemm))
 
 
 @pytest.mark.parametrize('gemm', GEMMS)
@@ -62,7 +70,7 @@ def test_strided_rays_match_the_oracle(scene, gemm):
     sub_t = torch.from_numpy(sub).to(DEV)
     z_all = dev(aux['all_zs'])
     ro, rd = d['rays_o'][:, sub_t].contiguous(), d['rays_d'][:, sub_t].contiguous()
-    if gemm == 'split_bf16':
+    if _split(d, gemm) is not None:
         _, taps = ops.field_eval_split(ro, rd, z_all, *geo, d['pf'], d['split'][1], return_taps=True)
     else:
         _, taps = ops.field_eval(ro, rd, z_all, *geo, d['pf'], return_taps=True)

@@ -115,12 +115,84 @@ def test_renderer_default_gemm_is_split_and_matches_mfma_f32():
     sc = make_scene(seed=71, height=16, width=16, n_rays=64, bias_scale=0.05)
     inputs = tuple(sc[k] for k in ['rays_o', 'rays_d', 'images', 'intrinsics', 'extrinsics_inv'])
     outs = {}
-    for gemm in ('split_bf16', 'mfma_f32'):
+    for gemm in ('split_f16', 'split_bf16', 'mfma_f32'):
         m = MVVNeRFRenderer(64, 64, n_views=1, near=sc['near'], far=sc['far'], device=DEV, f32_gemm=gemm)
         m.set_weights(sc['coarse'], sc['fine'])
         outs[gemm] = m._call(inputs, 64, 1, sc['features'], u_coarse=dev(sc['u_coarse']), u_fine=dev(sc['u_fine']))
-    assert MVVNeRFRenderer(64, 64, device=DEV).f32_gemm == 'split_bf16'
-    for a, b in zip(outs['split_bf16'], outs['mfma_f32']):
-        assert float((a - b).abs().max()) < 2e-5
+    assert MVVNeRFRenderer(64, 64, device=DEV).f32_gemm == 'split_f16'
+    for gemm in ('split_f16', 'split_bf16'):
+        for a, b in zip(outs[gemm], outs['mfma_f32']):
+            assert float((a - b).abs().max()) < 2e-5
+    assert not all(torch.equal(a, b) for a, b in zip(outs['split_f16'], outs['split_bf16']))       # really two kernels
     with pytest.raises(ValueError):
         MVVNeRFRenderer(64, 64, f32_gemm='tf32')
+
+
+def test_products_of_the_three_fp32_grade_kernels_against_float64(monkeypatch):
+    """How exact are the Dense layers of the three fp32 kernels?  Each ResNet block is recomputed in float64 FROM THE KERNEL'S OWN
+    input activation (complete_output), so the difference is that block's two GEMMs alone - no geometry, no positional encoding.
+    fp32 MFMA (v_mfma_f32_32x32x2_f32), six bf16 products on exactly cut operands (MVNERF_SPLIT_MFMA=bf16x6) and three fp16 products
+    on two-piece operands (f16x3) must all sit at fp32 rounding level, and the fp16 form within 2x of the fp32 MFMA."""
+    sc = make_scene(seed=91, n_views=1, height=24, width=28, n_rays=256, bias_scale=0.1)
+    d = {k: dev(sc[k]) for k in ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'fine']}
+    rng = np.random.default_rng(3)
+    z = dev(np.sort(rng.uniform(0.3, 1.3, (1, 256, 64)).astype(np.float32), -1))
+    packed, split = ops.pack_net(d['fine']), ops.pack_net_split(d['fine'])
+    args = (d['rays_o'], d['rays_d'], z, d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'], packed)
+    net = O.unflatten_net(sc['fine'])
+
+    def block64(x, blk):
+        w1, b1, w2, b2 = (np.asarray(a, np.float64) for a in blk)
+        x = x.astype(np.float64)
+        return x + np.maximum(np.maximum(x, 0) @ w1 + b1, 0) @ w2 + b2
+
+    def block_errors(acts):
+        a = [t.cpu().numpy().reshape(-1, 128) for t in acts]
+        errs = []
+        for k, blk in zip((0, 1, 2, 4, 5, 6), net['blocks']):
+            ref = block64(a[k], blk)
+            errs.append(np.abs(a[k + 1] - ref).max() / np.abs(ref).max())
+        return np.array(errs)
+
+    out = {}
+    _, acts = ops.field_eval(*args, complete_output=True)
+    out['fp32 mfma'] = block_errors(acts)
+    for mode, name in (('bf16x6', 'split_bf16'), ('f16x3', 'split_f16'), ('32x32x16', 'split_bf16_32x32x16')):
+        ops.set_split_kernel(name)
+        _, acts = ops.field_eval_split(*args, split, complete_output=True)
+        out[mode] = block_errors(acts)
+    monkeypatch.setenv('MVNERF_SPLIT_MFMA', 'bf16x6')                  # the environment variable overrides the setter
+    ops.set_split_kernel('split_f16')
+    _, acts = ops.field_eval_split(*args, split, complete_output=True)
+    assert np.array_equal(block_errors(acts), out['bf16x6'])
+    monkeypatch.delenv('MVNERF_SPLIT_MFMA')
+    for name, e in out.items():
+        print(f'{name:10s} per-block max |act - float64 block| / max |act|: ' + ' '.join(f'{v:.2e}' for v in e))
+    eps = 2.0 ** -24
+    for name, e in out.items():
+        assert e.max() < 16 * eps, (name, e)                  # a 128-term fp32 dot product, twice: a few ulps
+    assert out['f16x3'].max() < 2.0 * out['fp32 mfma'].max() + 2 * eps
+
+
+def test_pack_net_split_f16_pieces_represent_the_weights():
+    """The fp16 stream of the packed split image (behind the two bf16 streams; chunk = 24 kstep + 3 rb + piece): A0 = rn16(16 w),
+    A0s = A0 / 64, A1 = rn16(64 (16 w - A0)); (A0 + A1 / 64) / 16 reproduces w to 2^-23 |w| (+ 2^-30 absolute for tiny weights)."""
+    sc = make_scene(seed=2, height=8, width=8, n_rays=4, bias_scale=0.1)
+    net = dev(sc['fine'])
+    raw = ops.pack_net_split(net)
+    n16 = 58 * 24 * 1024                                                           # bytes of one 16x16x32 stream
+    f16 = raw[-n16:].view(torch.float16).view(58, 8, 3, 64, 8).double()            # (kstep, rb, piece, lane, jj)
+    a0, a0s, a1 = f16[:, :, 0], f16[:, :, 1], f16[:, :, 2]
+    assert ((a0s - a0 / 64).abs() <= 2.0 ** -25).all()                            # exact unless A0 / 64 is subnormal (|w| < 2.4e-4)
+    assert torch.equal(a0s[a0.abs() >= 2.0 ** -8], (a0 / 64)[a0.abs() >= 2.0 ** -8])
+    w1 = net[48640:48640 + 128 * 128].view(128, 128).double()
+    lane = torch.arange(64, device=DEV)
+    i, g = lane & 15, lane >> 4
+    jj = torch.arange(8, device=DEV)
+    for t in range(4):
+        f = 32 * t + torch.where(jj[None, :] < 4, 4 * g[:, None] + jj[None, :], 16 + 4 * g[:, None] + jj[None, :] - 4)   # (lane, jj)
+        for rb in (0, 3, 7):
+            want = w1[f, (16 * rb + i)[:, None].expand(64, 8)]
+            got = (a0[10 + t, rb] + a1[10 + t, rb] / 64) / 16
+            assert ((got - want).abs() <= 2.0 ** -23 * want.abs() + 2.0 ** -30).all(), (t, rb)
+            assert ((a0[10 + t, rb] / 16 - want).abs() <= 2.0 ** -11 * want.abs() + 2.0 ** -30).all()

@@ -79,6 +79,7 @@ SIGNATURES = {
     'mvnerf_readout': (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     'mvnerf_finish_view': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mvnerf_set_deterministic': (c_int, [c_int]),
+    'mvnerf_set_split_kernel': (c_int, [c_int]),
     'mvnerf_stash_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'mvnerf_field_backward_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'mvnerf_field_eval_stash': (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_void_p] * 4),

@@ -428,6 +428,12 @@ size_t mvnerf_field_backward_scratch_bytes(int B, int V, int R, int S) {
 
 int mvnerf_set_deterministic(int on) { return g_deterministic.exchange(on ? 1 : 0); }
 
+int mvnerf_set_split_kernel(int which) {
+    const int prev = mvnerf::set_split_kernel(which);
+    if (prev < 0) return fail(MVNERF_E_ARG, "mvnerf_set_split_kernel: which=%d (0 f16x3, 1 bf16x6, 2 bf16x6 as 32x32x16)", which);
+    return prev;
+}
+
 int mvnerf_field_eval_stash(const float* rays_o, const float* rays_d, const float* z, const float* images,
                             const float* features, const float* texel_table, const float* intrinsics,
                             const float* extrinsics_inv, const float* packed_net, int B, int V, int R, int S, int H, int W,

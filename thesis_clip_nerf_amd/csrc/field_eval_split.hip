@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 
 #include "mvnerf_kernels.h"
@@ -735,27 +736,41 @@ __global__ __launch_bounds__((kMultiView && MVS_MV_W4) ? 256 : 512, (kMultiView 
 
 }  // namespace
 
-// The packed_split buffer holds two weight streams: this kernel's (32x32x16 MFMA order, kSpChunks KiB) and, behind it, the
-// 16x16x32 kernel's (field_eval_split16.hip), which runs the inference passes.
+// The packed_split buffer holds three weight streams: this kernel's (32x32x16 MFMA order, kSpChunks KiB) and, behind it, the two of the
+// 16x16x32 kernels that run the inference passes (field_eval_split16.hip: three bf16 pieces; field_eval_split16h.hip: two fp16 pieces).
 hipError_t launch_pack_net_split(const float* net_keras, void* packed_split, hipStream_t st) {
     const int n = kSpChunks * kChunkElems;
     hipLaunchKernelGGL(pack_net_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, net_keras, static_cast<__bf16*>(packed_split));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_pack_net_split16(net_keras, static_cast<char*>(packed_split) + (size_t)kSpChunks * 1024, st);
+    if ((e = launch_pack_net_split16(net_keras, static_cast<char*>(packed_split) + (size_t)kSpChunks * 1024, st)) != hipSuccess) return e;
+    return launch_pack_net_split16h(net_keras, static_cast<char*>(packed_split) + (size_t)kSpChunks * 1024 + packed_net_split16_bytes(), st);
 }
 
-size_t packed_net_split_bytes() { return (size_t)kSpChunks * 1024 + packed_net_split16_bytes(); }
+size_t packed_net_split_bytes() { return (size_t)kSpChunks * 1024 + packed_net_split16_bytes() + packed_net_split16h_bytes(); }
 
-// MVNERF_SPLIT_MFMA=32x32x16 in the environment keeps every pass on this file's kernel (A/B runs and the tests that pin it)
-static bool split16_enabled() {
+// Which kernel runs a split field pass.  MVNERF_SPLIT_MFMA (read per launch: tests flip it inside one process):
+//   "32x32x16"  this file's kernel (round 2);   "bf16x6"  field_eval_split16.hip (exact three-piece bf16 cut, six products);
+//   "f16x3"     field_eval_split16h.hip (two fp16 pieces, three products; inference only);   unset: mvnerf_set_split_kernel's value
+//               (default f16x3).
+// The training forward (p.stash) always takes an exact-cut kernel.
+enum SplitKernel { kSplit16F16 = 0, kSplit16Bf16 = 1, kSplit32 = 2 };            // = MVNERF_SPLIT_* of include/mvnerf_hip.h
+static std::atomic<int> g_split_kernel{kSplit16F16};
+int set_split_kernel(int which) {
+    if (which < 0 || which > 2) return -1;
+    return g_split_kernel.exchange(which);
+}
+static SplitKernel split_kernel_choice() {
     const char* s = getenv("MVNERF_SPLIT_MFMA");
-    return !(s && s[0] == '3');
+    if (!s || !s[0]) return static_cast<SplitKernel>(g_split_kernel.load());
+    return s[0] == '3' ? kSplit32 : (s[0] == 'f' ? kSplit16F16 : kSplit16Bf16);
 }
 
 hipError_t launch_field_eval_split(const FieldParams& p, const void* packed_split, hipStream_t stream) {
-    if (split16_enabled() && field_eval_split16_supports(p))
-        return launch_field_eval_split16(p, static_cast<const char*>(packed_split) + (size_t)kSpChunks * 1024, stream);
+    const SplitKernel which = split_kernel_choice();
+    const char* base16 = static_cast<const char*>(packed_split) + (size_t)kSpChunks * 1024;
+    if (which == kSplit16F16 && !p.stash && field_eval_split16h_supports(p)) return launch_field_eval_split16h(p, base16 + packed_net_split16_bytes(), stream);
+    if (which != kSplit32 && field_eval_split16_supports(p)) return launch_field_eval_split16(p, base16, stream);
     static std::mutex mtx;
     static bool attr_done[16] = {};
     static int cus[16] = {};

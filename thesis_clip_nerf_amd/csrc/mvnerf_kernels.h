@@ -69,6 +69,12 @@ size_t packed_net_split16_bytes();
 hipError_t launch_pack_net_split16(const float* net_keras, void* packed_split16, hipStream_t st);
 bool field_eval_split16_supports(const FieldParams& p);
 hipError_t launch_field_eval_split16(const FieldParams& p, const void* packed_split16, hipStream_t stream);
+int set_split_kernel(int which);          // field_eval_split.hip: which of the three split kernels runs (returns the previous value)
+// field_eval_split16h.hip: the same kernel body on two fp16 pieces per operand, three v_mfma_f32_16x16x32_f16 per product block
+size_t packed_net_split16h_bytes();
+hipError_t launch_pack_net_split16h(const float* net_keras, void* packed_split16h, hipStream_t st);
+bool field_eval_split16h_supports(const FieldParams& p);
+hipError_t launch_field_eval_split16h(const FieldParams& p, const void* packed_split16h, hipStream_t stream);
 
 // grasp_head.hip: the per-point part of GraspReadout (value, VJP, derivative of the VJP)
 size_t grasp_head_packed_floats();

@@ -37,7 +37,7 @@ class MVVNeRFRenderer:
 
     def __init__(self, n_rays_train, n_rays_infer, n_views=2, n_samples=64, n_features=256,
                  embed_direction_vector=True, batch_size=1, near=0.7, far=1.5, original_image_size=(480, 640),
-                 device='cuda', seed=0, feature_encoder=None, q7_mode=Q7_ZERO, compute_dtype='f32', f32_gemm='split_bf16'):
+                 device='cuda', seed=0, feature_encoder=None, q7_mode=Q7_ZERO, compute_dtype='f32', f32_gemm='split_f16'):
         if n_features != 256:
             raise ValueError('n_features must be 256 (the HIP kernels are built for the reference feature width)')
         if not embed_direction_vector:
@@ -59,8 +59,9 @@ class MVVNeRFRenderer:
         if compute_dtype not in ('f32', 'bf16'):
             raise ValueError("compute_dtype must be 'f32' (reference precision) or 'bf16' (bf16 MFMA inputs, fp32 accumulate)")
         self.compute_dtype = compute_dtype       # inference only; training always runs the fp32 path
-        if f32_gemm not in ('split_bf16', 'mfma_f32'):
-            raise ValueError("f32_gemm must be 'split_bf16' (six bf16 MFMAs per product on exactly cut operands, fp32-grade) or 'mfma_f32'")
+        if f32_gemm not in ('split_f16', 'split_bf16', 'mfma_f32'):
+            raise ValueError("f32_gemm must be 'split_f16' (two fp16 pieces per operand, three MFMAs per product block: the default), "
+                             "'split_bf16' (exact three-piece bf16 cut, six MFMAs) - both fp32-grade - or 'mfma_f32'")
         self.f32_gemm = f32_gemm                 # how compute_dtype='f32' inference runs its Dense layers (same results to ~1e-6)
         rng = np.random.default_rng(seed)
         self.coarse_net = torch.from_numpy(glorot_net(rng)).to(self.device)      # Keras glorot_uniform, zero bias
@@ -165,9 +166,11 @@ class MVVNeRFRenderer:
             tables = self._tables
             ready = scene_key is not None and self._tables_key == scene_key
             self._tables_key = scene_key
+        if self.f32_gemm != 'mfma_f32':
+            ops.set_split_kernel(self.f32_gemm)          # process-wide: which split kernel the calls below run
         return ops.render_fwd(rays_o, rays_d, images, features, k4, einv, pc, pf, self._dev(u_coarse), self._dev(u_fine),
                               self.near, self.far, self.q7_mode, workspace=self._workspace, texel_tables=tables,
-                              tables_ready=ready, split=self.packed_split() if self.f32_gemm == 'split_bf16' else None)
+                              tables_ready=ready, split=self.packed_split() if self.f32_gemm != 'mfma_f32' else None)
 
     def infer(self, inputs, batched_features, **kw):
         """model_v0.py:61-63 (any ray count, not only n_rays_infer=512)."""
@@ -246,7 +249,7 @@ class MVVNeRFRenderer:
         pc, pf = self.packed()
         if self._packed_bwd is None:
             self._packed_bwd = (ops.pack_bwd_streams(self.coarse_net), ops.pack_bwd_streams(self.fine_net))
-        split = self.packed_split() if self.f32_gemm == 'split_bf16' else None
+        split = self.packed_split() if self.f32_gemm != 'mfma_f32' else None      # the training forward always takes an exact-cut kernel
         use_tables = ops.texel_table_pays(r, self.n_samples, h, w)      # layer 0's feature rows per texel
         tb = self._train_bufs
         key = (b, v, r, h, w, bool(return_d_features))

@@ -738,6 +738,19 @@ def gemm_tn(g, a):
     return out
 
 
+SPLIT_KERNELS = {'split_f16': 0, 'split_bf16': 1, 'split_bf16_32x32x16': 2}
+
+
+def set_split_kernel(name):
+    """mvnerf_set_split_kernel: which kernel runs the split field passes of this process - 'split_f16' (default: two fp16 pieces per
+    operand, three MFMAs per product block), 'split_bf16' (exact three-piece bf16 cut, six MFMAs) or 'split_bf16_32x32x16' (round 2's
+    kernel).  Returns the previous name.  The environment variable MVNERF_SPLIT_MFMA overrides it at every launch."""
+    if name not in SPLIT_KERNELS:
+        raise ValueError(f'split kernel must be one of {sorted(SPLIT_KERNELS)}, got {name!r}')
+    prev = int(_lib.lib().mvnerf_set_split_kernel(SPLIT_KERNELS[name]))
+    return {v: k for k, v in SPLIT_KERNELS.items()}[prev]
+
+
 def set_deterministic(on=True):
     """mvnerf_set_deterministic.  Weight gradients are ALWAYS summed in a fixed order since round 2 (stored per-workgroup partials +
     a parallel fixed-order reduction turned out faster than fp32 atomics); the call is kept for its callers, records the flag and
