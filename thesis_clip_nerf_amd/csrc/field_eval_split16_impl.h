@@ -22,14 +22,17 @@
 //
 // This file is the body of TWO translation units (field_eval_split16.hip: MVS16_F16 = 0, field_eval_split16h.hip: MVS16_F16 = 1):
 //   MVS16_F16 = 0  operands cut EXACTLY into three bf16 pieces, six v_mfma_f32_16x16x32_bf16 per product block (as described above);
-//   MVS16_F16 = 1  operands as TWO fp16 pieces, three v_mfma_f32_16x16x32_f16 per product block: with tw = 16 w, tv = v / 16
-//                  (powers of two: exact)  A0 = rn16(tw), A1 = rn16(64 (tw - A0)), A0s = A0 / 64;  B0 = rn16(tv), B1 = rn16(64 (tv - B0)),
-//                  B0s = B0 / 64;  acc += A0s B1 + A1 B0s + A0 B0 = w v - (tw - A0 - A1/64)(...) - r_a r_b: the operands are
-//                  represented to 22-24 significant bits (round-to-nearest twice: |error| <= 2^-23 |x|), the one dropped cross term is
-//                  <= 2^-22 |w v| (2^-25 typical), and every piece stays a NORMAL fp16 number for |w| >= 2.4e-4, |v| >= 0.06 - below that
-//                  the pieces go subnormal (the MFMA honours fp16 subnormals: scripts/f16_mfma_probe.hip) with absolute errors
-//                  <= 2^-26 |w| per product.  Same stream size (three 1 KiB pieces per row block), same registers, half the MFMAs.
-//                  Range: |w| < 4094, |v| < 1.04e6 (fp16 overflow beyond; the bf16 form has the full fp32 range).
+//   MVS16_F16 = 1  operands as TWO fp16 pieces, three v_mfma_f32_16x16x32_f16 per product block.  With tw = 64 w and tv = v / 64 (powers
+//                  of two: exact, tw tv = w v):  A0 = rn16(tw), A1 = rn16(tw - A0), A0s = A0 / 64;  B0 = rn16(tv), B1 = rn16(64 (tv - B0))
+//                  = rn16(v - 64 B0);  acc += A0s B1 + A1 B0 + A0 B0.  Both remainders are exact in fp32 before they are rounded, so each
+//                  operand is represented to 22-24 significant bits (|error| <= 2^-23 |x|); the one dropped cross term (tw - A0)(tv - B0)
+//                  is <= 2^-22 |w v| (2^-25 typical).  The activation's remainder is scaled by 64 (and meets A0 / 64) so that it stays a
+//                  normal fp16 number down to |v| = 2^-3; below that, and for the weights' unscaled remainder below |w| = 2^-9, the
+//                  pieces go subnormal - the MFMA honours fp16 subnormals (scripts/f16_mfma_probe.hip) - with absolute errors <= 2^-25 |w|
+//                  resp. 2^-31 |v| per product.  Measured per ResNet block against float64: at or below the fp32 MFMA kernel's error
+//                  (tests/test_gpu_split.py).  Same stream size (three 1 KiB weight pieces per row block), two instead of three operand
+//                  pieces in registers, half the MFMAs.  Range: |w| < 1023, |v| < 4.19e6 (fp16 overflow beyond; the bf16 form has the full
+//                  fp32 range).
 #include <hip/hip_runtime.h>
 
 #include <mutex>
@@ -103,10 +106,10 @@ __global__ void MVS16_PACK_KERNEL(const float* __restrict__ src, unsigned short*
         val = src[wsrc + f * kHidden + 16 * rb + i];
     }
 #if MVS16_F16
-    // piece 0: A0 = rn16(16 w); piece 1: A0s = A0 / 64; piece 2: A1 = rn16(64 (16 w - A0)) (the remainder is exact in fp32)
-    const float tw = val * 16.0f;
+    // piece 0: A0 = rn16(64 w); piece 1: A0s = A0 / 64; piece 2: A1 = rn16(64 w - A0) (the remainder is exact in fp32)
+    const float tw = val * 64.0f;
     const _Float16 a0 = (_Float16)tw;
-    const _Float16 a1 = (_Float16)((tw - (float)a0) * 64.0f);
+    const _Float16 a1 = (_Float16)(tw - (float)a0);
     const _Float16 a0s = (_Float16)((float)a0 * 0.015625f);
     const _Float16 pc = piece == 0 ? a0 : (piece == 1 ? a0s : a1);
     dst[idx] = __builtin_bit_cast(unsigned short, pc);
@@ -144,18 +147,16 @@ __device__ __forceinline__ void cut_pair(float v0, float v1, int q, B16& b) {
         v1 = __builtin_bit_cast(float, i1 > 0 ? i1 : 0);
     }
 #if MVS16_F16
-    // p1 = B0 = rn16(v / 16), p2 = B0s = B0 / 64, p3 = B1 = rn16(64 (v / 16 - B0)) = rn16(4 v - 64 B0): the remainder is exact in fp32,
-    // formed by one mixed-precision fma per value (v_fma_mix_f32 reads B0's halves as they lie)
-    const f32x2 t = {v0 * 0.0625f, v1 * 0.0625f};
-    const f32x2 t64 = {v0 * 4.0f, v1 * 4.0f};
-    const f16x2 h = __builtin_convertvector(t, f16x2);
-    const f32x2 r = {__builtin_fmaf((float)h[0], -64.0f, t64[0]), __builtin_fmaf((float)h[1], -64.0f, t64[1])};
-    const f16x2 l = __builtin_convertvector(r, f16x2);
-    const f16x2 k64 = {(_Float16)0.015625f, (_Float16)0.015625f};
-    const f16x2 hs = h * k64;
-    b.p1[q] = __builtin_bit_cast(unsigned, h);
-    b.p2[q] = __builtin_bit_cast(unsigned, hs);
-    b.p3[q] = __builtin_bit_cast(unsigned, l);
+    // p1 = B0 = rn16(v / 64), p3 = B1 = rn16(64 (v / 64 - B0)) = rn16(v - 64 B0): the remainder is exact in fp32, formed by one
+    // mixed-precision fma per value (v_fma_mix_f32 reads B0's halves as they lie); p2 is not used
+    const f32x2 t = {v0 * 0.015625f, v1 * 0.015625f};
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t, f16x2));
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "s"(-64.0f), "v"(v0));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "s"(-64.0f), "v"(v1));
+    const f32x2 r = {r0, r1};
+    b.p1[q] = h;
+    b.p3[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 #else
     const float r0 = v0 - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v0) & 0xffff0000u);
     const float r1 = v1 - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v1) & 0xffff0000u);
@@ -164,6 +165,22 @@ __device__ __forceinline__ void cut_pair(float v0, float v1, int q, B16& b) {
     b.p1[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, v1), __builtin_bit_cast(unsigned, v0), 0x07060302u);
     b.p2[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, r1), __builtin_bit_cast(unsigned, r0), 0x07060302u);
     b.p3[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+#endif
+}
+
+// keeps dword q of an operand's pieces where the program order has them (an empty asm the scheduler cannot move code across)
+__device__ __forceinline__ void pin_pieces(B16& b, int q) {
+#if MVS16_F16
+    unsigned u1 = b.p1[q], u3 = b.p3[q];
+    asm volatile("" : "+v"(u1), "+v"(u3));
+    b.p1[q] = u1;
+    b.p3[q] = u3;
+#else
+    unsigned u1 = b.p1[q], u2 = b.p2[q], u3 = b.p3[q];
+    asm volatile("" : "+v"(u1), "+v"(u2), "+v"(u3));
+    b.p1[q] = u1;
+    b.p2[q] = u2;
+    b.p3[q] = u3;
 #endif
 }
 
@@ -320,11 +337,7 @@ __device__ __forceinline__ void kstep16(Ring16& ring, int lane, int g, const B16
                     cut_pair<true>(acc[q >> 1][cb][2 * (q & 1)], acc[q >> 1][cb][2 * (q & 1) + 1], q, bn[cb]);
                     // pinned inside its group: this cut reads MFMA results, and left to itself the scheduler fills the group's vector
                     // slots with the bias adds and sinks the whole cut behind the k-step's last MFMA
-                    unsigned u1 = bn[cb].p1[q], u2 = bn[cb].p2[q], u3 = bn[cb].p3[q];
-                    asm volatile("" : "+v"(u1), "+v"(u2), "+v"(u3));
-                    bn[cb].p1[q] = u1;
-                    bn[cb].p2[q] = u2;
-                    bn[cb].p3[q] = u3;
+                    pin_pieces(bn[cb], q);
                 }
             }
             if (tail_bias) {
@@ -336,11 +349,11 @@ __device__ __forceinline__ void kstep16(Ring16& ring, int lane, int g, const B16
             }
         }
 #if MVS16_F16
-        // three products per block, the two small ones first: A0s B1, A1 B0s, A0 B0 (a = {A0, A0s, A1}, b = {B0, B0s, B1})
+        // three products per block, the two small ones first: A0s B1, A1 B0, A0 B0 (a = {A0, A0s, A1}, b = {p1: B0, p3: B1})
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma1632(a[1], b[cb].p3, acc[rb][cb]);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma1632(a[2], b[cb].p2, acc[rb][cb]);
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma1632(a[2], b[cb].p1, acc[rb][cb]);
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma1632(a[0], b[cb].p1, acc[rb][cb]);
 #elif MVS16_ORDER == 1
@@ -400,11 +413,7 @@ __device__ __forceinline__ void kstep16(Ring16& ring, int lane, int g, const B16
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                unsigned u1 = bn[cb].p1[q], u2 = bn[cb].p2[q], u3 = bn[cb].p3[q];
-                asm volatile("" : "+v"(u1), "+v"(u2), "+v"(u3));
-                bn[cb].p1[q] = u1;
-                bn[cb].p2[q] = u2;
-                bn[cb].p3[q] = u3;
+                pin_pieces(bn[cb], q);
             }
     }
 }
