@@ -315,6 +315,7 @@ __device__ __forceinline__ void apply_bias_row(f32x4 (&row)[2], const f32x4& bv)
 //            0 and 1 of acc, final after groups 0 and 1 (relu, then the cut) - during groups 1..4, and the layer's input array, no
 //            longer needed, takes the bias work of the layer boundary (tail_bias: in[rb][cb] += bias row, or = bias row), one row
 //            block per group.  With it no vector work of a layer boundary is left outside the MFMA shadow.
+//   kMode 4: the last k-step of a hidden layer in the plain flow: only the bias half of kMode 2 (tail_bias onto the consumed input array).
 //   kMode 0: nothing.
 template <bool kRelu, int kMode, bool kTailAdd, bool kDma>
 __device__ __forceinline__ void kstep16(Ring16& ring, int lane, int g, const B16 (&b)[2], const float (&nv)[2][8], B16 (&bn)[2], f32x4 (&acc)[8][2],
@@ -323,6 +324,11 @@ __device__ __forceinline__ void kstep16(Ring16& ring, int lane, int g, const B16
     const f32x4* nxt = ring16_nxt(ring) + lane;
     u32x4 a[3] = {ring.a0[0], ring.a0[1], ring.a0[2]};
     f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+    // the lane's part of perm_f4, formed HERE (behind an empty asm): left to itself the compiler hoists the eight row addresses of every
+    // layer's bias vector out of the tile loop and spills them
+    int glane = (g & 1) * 16 + (g >> 1);
+    if (kMode == 2 || kMode == 4) asm volatile("" : "+v"(glane));
+    const f32x4* tail_rows = reinterpret_cast<const f32x4*>(tail_bias) + glane;
 #pragma unroll
     for (int rb = 0; rb < 8; ++rb) {
         u32x4 an[3];
@@ -340,13 +346,13 @@ __device__ __forceinline__ void kstep16(Ring16& ring, int lane, int g, const B16
                     pin_pieces(bn[cb], q);
                 }
             }
-            if (tail_bias) {
-                // the bias row of row block rb is requested here and applied one group later (an LDS round trip inside a group would
-                // hold this wave's MFMAs behind the wait); row 7 is applied behind the last group
-                const f32x4 bv_new = reinterpret_cast<const f32x4*>(tail_bias)[perm_f4(rb, g)];
-                if (rb > 0) apply_bias_row<kTailAdd>(in[rb - 1], bv);
-                bv = bv_new;
-            }
+        }
+        if ((kMode == 2 || kMode == 4) && tail_bias) {
+            // the bias row of row block rb is requested here and applied one group later (an LDS round trip inside a group would
+            // hold this wave's MFMAs behind the wait); row 7 is applied behind the last group
+            const f32x4 bv_new = tail_rows[(rb >> 1) * 4 + 2 * (rb & 1)];              // = [perm_f4(rb, g)]: the row block is an immediate offset
+            if (rb > 0) apply_bias_row<kTailAdd>(in[rb - 1], bv);
+            bv = bv_new;
         }
 #if MVS16_F16
         // three products per block, the two small ones first: A0s B1, A1 B0, A0 B0 (a = {A0, A0s, A1}, b = {p1: B0, p3: B1})
@@ -387,11 +393,12 @@ __device__ __forceinline__ void kstep16(Ring16& ring, int lane, int g, const B16
         // issue order inside the group: the first MFMA (its operands were requested one group ago), the LDS reads of the next group
         // (and the bias row), then vector instructions / MFMA alternating
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, kMode == 2 ? 4 : 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, (kMode == 2 || kMode == 4) ? 4 : 3, 0);
 #pragma unroll
         for (int m = 0; m < (MVS16_F16 ? 5 : 11); ++m) {
             if (kMode == 1) __builtin_amdgcn_sched_group_barrier(0x002, MVS16_F16 ? 2 : 1, 0);
             if (kMode == 2) __builtin_amdgcn_sched_group_barrier(0x002, MVS16_F16 ? 6 : 3, 0);
+            if (kMode == 4) __builtin_amdgcn_sched_group_barrier(0x002, MVS16_F16 ? 2 : 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
         if (kMode == 1) __builtin_amdgcn_sched_group_barrier(0x002, MVS16_F16 ? 3 : 2, 0);
@@ -406,8 +413,8 @@ __device__ __forceinline__ void kstep16(Ring16& ring, int lane, int g, const B16
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q) ring.a0[q] = a[q];
-    if (kMode == 2 && tail_bias) apply_bias_row<kTailAdd>(in[7], bv);
-    if (kMode != 0) {
+    if ((kMode == 2 || kMode == 4) && tail_bias) apply_bias_row<kTailAdd>(in[7], bv);
+    if (kMode == 1 || kMode == 2) {
         // pin the pieces of the next operand HERE (otherwise the machine sinker moves the cut behind the barrier)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
@@ -431,13 +438,19 @@ __device__ __forceinline__ void first_operand_s16(const f32x4 (&in)[8][2], B16 (
 // b: on entry the cut of relu(in[0..1]) (first_operand_s16, or the previous layer's exit value); on exit the cut of relu(acc[0..1]),
 // i.e. the next layer's entry value.  tail_bias (or nullptr): in the last k-step in[rb][cb] += / = that bias vector (32x32 accumulator
 // order) - `x += b2` while the first Dense of a block writes hid, `hid = b1 of the next block` while the second one writes x.
+#ifndef MVS16_TAILBIAS
+#define MVS16_TAILBIAS 0   // 1: plain flow with the bias rows of the next layer's accumulator applied in the last k-step of the current layer (kMode 4).
+                           //    Measured on the fp16 form (profiles/r03_ab_tailbias.log): +0.3 %, i.e. nothing - the layer boundaries' vector work is not what it waits for
+#endif
 #ifndef MVS16_TAIL
 #define MVS16_TAIL 0       // 1: layer boundaries prepared in the previous layer's last k-step (kMode 2); 0: their vector work (first operand's
 #endif                     //    cut, bias rows) stays between the layers.  Measured (profiles/r03_ab_tail*.log): 1 is 3-5 % SLOWER - see DESIGN.md 4.0
 
-// the plain form: acc += W^T relu(in), first operand cut at the layer's head
-template <bool kDma>
-__device__ __forceinline__ void dense128_s16_plain(Ring16& ring, int lane, int g, f32x4 (&in)[8][2], f32x4 (&acc)[8][2]) {
+// the plain form: acc += W^T relu(in), first operand cut at the layer's head.  tail_bias (or nullptr): during the last k-step, when every
+// row of `in` has been cut, in[rb][cb] += / = that bias vector (32x32 accumulator order) - `x += b2` while the first Dense of a block writes
+// hid, `hid = b1 of the next block` while the second one writes x: the bias rows of the NEXT layer's accumulator cost no exposed time.
+template <bool kDma, bool kTailAdd>
+__device__ __forceinline__ void dense128_s16_plain(Ring16& ring, int lane, int g, f32x4 (&in)[8][2], f32x4 (&acc)[8][2], const float* __restrict__ tail_bias) {
     B16 b[2], bn[2];
     first_operand_s16(in, b);
 #pragma unroll
@@ -448,7 +461,7 @@ __device__ __forceinline__ void dense128_s16_plain(Ring16& ring, int lane, int g
 #pragma unroll
             for (int q = 0; q < 8; ++q) nv[cb][q] = t < 3 ? in[2 * (t + 1) + (q >> 2)][cb][q & 3] : 0.0f;
         if (t < 3) kstep16<true, 1, false, kDma>(ring, lane, g, b, nv, bn, acc, in, nullptr);
-        else kstep16<true, 0, false, kDma>(ring, lane, g, b, nv, bn, acc, in, nullptr);
+        else kstep16<true, 4, kTailAdd, kDma>(ring, lane, g, b, nv, bn, acc, in, tail_bias);
         b[0] = bn[0];
         b[1] = bn[1];
         ring16_next<kDma>(ring);
@@ -619,7 +632,11 @@ __global__ __launch_bounds__(512, 2) void MVS16_KERNEL(FieldParams p, const f32x
         (void)bop;
 
         // (a sample row of 128 floats: lane (n, g) holds features 16 rb + 4g + {0..3} of samples n (cb 0) and 16 + n (cb 1))
-        for (int v = 0; v < p.V; ++v) {
+        // the launcher sends V = 1 to the !kMultiView variants.  Telling the compiler so takes the optional-output and stash variants from 92-132
+        // to 0 B/lane of scratch (hid is no longer carried around a loop it cannot see is a single trip) - and costs the plain variant 56 B,
+        // which therefore keeps the runtime bound
+        const int n_views = (kMultiView || !(kAux || kStash)) ? p.V : 1;
+        for (int v = 0; v < n_views; ++v) {
             int tl[2];
             float ax[2], ay[2];
             long vrow[2];
@@ -819,7 +836,10 @@ __global__ __launch_bounds__(512, 2) void MVS16_KERNEL(FieldParams p, const f32x
             // ---- 24 k-steps: the three per-view ResNet blocks.  Only this entry is a layer boundary with exposed vector work (the
             // first operand's cut and the first bias row): every later boundary is prepared in the previous layer's last k-step ----
 #if MVS16_TAIL
-            if (v == 0) bias16<false>(net + kPackBHidden, g, hid);               // later views: set by the previous view's last tail
+            if (v == 0)
+#endif
+            bias16<false>(net + kPackBHidden, g, hid);      // exposed once per (tile, view); the later layers' bias rows are applied in k-step shadows
+#if MVS16_TAIL
             first_operand_s16(x, bop);
 #endif
 #pragma unroll 1
@@ -831,11 +851,21 @@ __global__ __launch_bounds__(512, 2) void MVS16_KERNEL(FieldParams p, const f32x
                 const float* next_b1 = bi < 2 ? bias1 + 256 : net + kPackBHidden + ((kMultiView && v + 1 < p.V) ? 0 : 768);
                 dense128_s16<false>(ring, lane, g, hid, x, bop, next_b1);
 #else
-                bias16<false>(bias1, g, hid);
-                dense128_s16_plain<kDma>(ring, lane, g, x, hid);
+                // hid = b1 + W1^T relu(x), and in its last k-step x += b2; x += W2^T relu(hid), and in its last k-step hid = b1 of the
+                // block that follows (the last view hands over to fusion block 3)
+                // (a view that is followed by another one leaves hid alone: carried through the next view's sin / cos and gather it would be spilled)
+#if MVS16_TAILBIAS
+                const float* next_b1 = bi < 2 ? bias1 + 256 : (v + 1 == n_views ? net + kPackBHidden + 768 : nullptr);
+                dense128_s16_plain<kDma, true>(ring, lane, g, x, hid, bias1 + 128);
+                if (kStash && tile_ok) store_tl16(p.stash + (1 + 2 * bi) * p.stash_stride, vtile, n, g, hid);
+                dense128_s16_plain<kDma, false>(ring, lane, g, hid, x, next_b1);
+#else
+                if (bi > 0) bias16<false>(bias1, g, hid);
+                dense128_s16_plain<kDma, true>(ring, lane, g, x, hid, nullptr);
                 if (kStash && tile_ok) store_tl16(p.stash + (1 + 2 * bi) * p.stash_stride, vtile, n, g, hid);
                 bias16<true>(bias1 + 128, g, x);
-                dense128_s16_plain<kDma>(ring, lane, g, hid, x);
+                dense128_s16_plain<kDma, false>(ring, lane, g, hid, x, nullptr);
+#endif
                 // (per-view slot 6 = x3 is not written: nothing reads it, as in field_eval_split_kernel)
                 if (kStash && tile_ok && bi < 2) store_tl16(p.stash + (2 + 2 * bi) * p.stash_stride, vtile, n, g, x);
 #endif
@@ -891,11 +921,17 @@ __global__ __launch_bounds__(512, 2) void MVS16_KERNEL(FieldParams p, const f32x
             dense128_s16<true>(ring, lane, g, x, hid, bop, bias1 + 128);
             dense128_s16<false>(ring, lane, g, hid, x, bop, bi < 5 ? bias1 + 256 : nullptr);
 #else
+#if MVS16_TAILBIAS
+            dense128_s16_plain<kDma, true>(ring, lane, g, x, hid, bias1 + 128);
+            if (kStash && tile_ok) store_tl16(p.stash_fused + (1 + 2 * (bi - 3)) * p.stash_fused_stride, tile, n, g, hid);
+            dense128_s16_plain<kDma, false>(ring, lane, g, hid, x, bi < 5 ? bias1 + 256 : nullptr);
+#else
             bias16<false>(bias1, g, hid);
-            dense128_s16_plain<kDma>(ring, lane, g, x, hid);
+            dense128_s16_plain<kDma, true>(ring, lane, g, x, hid, nullptr);
             if (kStash && tile_ok) store_tl16(p.stash_fused + (1 + 2 * (bi - 3)) * p.stash_fused_stride, tile, n, g, hid);
             bias16<true>(bias1 + 128, g, x);
-            dense128_s16_plain<kDma>(ring, lane, g, hid, x);
+            dense128_s16_plain<kDma, false>(ring, lane, g, hid, x, nullptr);
+#endif
             if (kStash && tile_ok) store_tl16(p.stash_fused + (2 + 2 * (bi - 3)) * p.stash_fused_stride, tile, n, g, x);
 #endif
             if (kAux && p.acts_fused) store_fused16(p.acts_fused + (long)(bi - 2) * p.total * 128);
