@@ -1,11 +1,11 @@
 #!/bin/bash
-# SQ-level counters for the split-bf16 field kernel (separate passes). Usage (via gpurun): bash scripts/pmc_split.sh <outdir> [bench args]
+# SQ-level counters for the split field kernel (separate passes; GEMM=split_f16 (default) | split_bf16). Usage (via gpurun): bash scripts/pmc_split.sh <outdir> [bench args]
 set -u
 OUT=${1:-gpurun_out/pmc_split}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 run() { local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python bench.py --f32-gemm split_bf16 --steps 3 --warmup 1 --cpu-baseline off --train-steps 0 "${BENCH_ARGS[@]}" > "$OUT/$name.log" 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python bench.py --f32-gemm ${GEMM:-split_f16} --steps 3 --warmup 1 --cpu-baseline off --train-steps 0 "${BENCH_ARGS[@]}" > "$OUT/$name.log" 2>&1
   echo "$name rc=$?"; }
 BENCH_ARGS=("$@")
 run act SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES GRBM_GUI_ACTIVE

@@ -56,7 +56,7 @@
 #define MVS16_PACK launch_pack_net_split16
 #define MVS16_SUPPORTS field_eval_split16_supports
 #define MVS16_LAUNCH_FN launch_field_eval_split16
-#define MVS16_KERNEL MVS16_KERNEL
+#define MVS16_KERNEL field_eval_split16_kernel
 #define MVS16_PACK_KERNEL pack_net_split16_kernel
 #endif
 
