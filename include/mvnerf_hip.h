@@ -157,12 +157,13 @@ int mvnerf_field_eval_bf16maps(const float* rays_o, const float* rays_d, const f
  * (mvnerf_set_split_kernel):
  *   MVNERF_SPLIT_F16X3 (default)  two fp16 pieces per operand (round-to-nearest twice, the remainder scaled by 64: 22-24 significant
  *                                 bits), three v_mfma_f32_16x16x32_f16 per block; per ResNet block as close to a float64 evaluation as
- *                                 the fp32 MFMA (tests/test_gpu_split.py); range |w| < 4094, |activation| < 1.04e6
- *                                 (csrc/field_eval_split16_impl.h, field_eval_split16h.hip); inference only
+ *                                 the fp32 MFMA (tests/test_gpu_split.py); range |w| < 1023, |activation| < 4.19e6
+ *                                 (csrc/field_eval_split16_impl.h, field_eval_split16h.hip)
  *   MVNERF_SPLIT_BF16X6           three bf16 pieces per operand, an EXACT cut, the six products of order >= 2^-16 as
  *                                 v_mfma_f32_16x16x32_bf16; dropped terms <= 2^-24 relative; full fp32 range (field_eval_split16.hip)
  *   MVNERF_SPLIT_BF16X6_32        the same products as v_mfma_f32_32x32x16_bf16 (round 2's kernel, field_eval_split.hip)
- * The training forward (mvnerf_field_eval_stash_split) always uses an exact-cut kernel. ---- */
+ * The training forward (mvnerf_field_eval_stash_split) follows the same choice (the 32x32x16 kernel has no fp16 form: it and the backward
+ * keep the exact cut). ---- */
 #define MVNERF_SPLIT_F16X3 0
 #define MVNERF_SPLIT_BF16X6 1
 #define MVNERF_SPLIT_BF16X6_32 2

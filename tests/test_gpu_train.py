@@ -161,15 +161,16 @@ def test_sample_position_gradient_through_the_texel_table_matches_the_recomputed
     a, b = grads[True][:247300], grads[False][:247300]              # the coarse net sees dL/dz of the fine pass
     assert np.linalg.norm(b) > 0
     # (the forward value itself differs in the last bits with and without the table, and this term has a gain of pi * 2^9 through
-    # the positional encoding: torch's own fp32 autograd is 1.8e-2 away from fp64 on such scenes; measured here 1e-3 .. 2e-3)
-    assert np.linalg.norm(a - b) < 1e-2 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
+    # the positional encoding: torch's own fp32 autograd is 1.8e-2 away from fp64 on such scenes.  Measured over three scenes and the two
+    # forward kernels (scripts/dz_probe.py): 7.6e-4 .. 1.4e-2, whichever kernel - any last-bit change of the forward moves it that much)
+    assert np.linalg.norm(a - b) < 3e-2 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
     # and the two differ from the gradient with the fine depths held constant, i.e. the term is really there
     monkeypatch.setattr(ops, 'texel_table_pays', lambda *a: True)
     m = MVVNeRFRenderer(32, 32, n_views=views, batch_size=batch, near=sc['near'], far=sc['far'], device=DEV)
     m.set_weights(sc['coarse'], sc['fine'])
     _, grad_cut, _ = m.loss_and_grads(inputs, y, sc['features'], u_coarse=dev(sc['u_coarse']), u_fine=dev(sc['u_fine']), stop_fine_z=True)
     cut = grad_cut.cpu().numpy()[:247300]
-    assert np.linalg.norm(a - b) < 0.05 * np.linalg.norm(a - cut)
+    assert np.linalg.norm(a - b) < 0.1 * np.linalg.norm(a - cut)
 
 
 def test_train_step_reduces_loss_and_respects_q9():

@@ -751,9 +751,8 @@ size_t packed_net_split_bytes() { return (size_t)kSpChunks * 1024 + packed_net_s
 
 // Which kernel runs a split field pass.  MVNERF_SPLIT_MFMA (read per launch: tests flip it inside one process):
 //   "32x32x16"  this file's kernel (round 2);   "bf16x6"  field_eval_split16.hip (exact three-piece bf16 cut, six products);
-//   "f16x3"     field_eval_split16h.hip (two fp16 pieces, three products; inference only);   unset: mvnerf_set_split_kernel's value
+//   "f16x3"     field_eval_split16h.hip (two fp16 pieces, three products);   unset: mvnerf_set_split_kernel's value
 //               (default f16x3).
-// The training forward (p.stash) always takes an exact-cut kernel.
 enum SplitKernel { kSplit16F16 = 0, kSplit16Bf16 = 1, kSplit32 = 2 };            // = MVNERF_SPLIT_* of include/mvnerf_hip.h
 static std::atomic<int> g_split_kernel{kSplit16F16};
 int set_split_kernel(int which) {
@@ -769,7 +768,7 @@ static SplitKernel split_kernel_choice() {
 hipError_t launch_field_eval_split(const FieldParams& p, const void* packed_split, hipStream_t stream) {
     const SplitKernel which = split_kernel_choice();
     const char* base16 = static_cast<const char*>(packed_split) + (size_t)kSpChunks * 1024;
-    if (which == kSplit16F16 && !p.stash && field_eval_split16h_supports(p)) return launch_field_eval_split16h(p, base16 + packed_net_split16_bytes(), stream);
+    if (which == kSplit16F16 && field_eval_split16h_supports(p)) return launch_field_eval_split16h(p, base16 + packed_net_split16_bytes(), stream);
     if (which != kSplit32 && field_eval_split16_supports(p)) return launch_field_eval_split16(p, base16, stream);
     static std::mutex mtx;
     static bool attr_done[16] = {};

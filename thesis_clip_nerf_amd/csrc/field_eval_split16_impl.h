@@ -193,6 +193,11 @@ __device__ __forceinline__ void cut8(const float (&v)[8], B16& b) {
 #ifndef MVS16_ORDER
 #define MVS16_ORDER 0      // order of the six products of a block (A/B experiment, see kstep16)
 #endif
+#ifndef MVS16_DMA_LATE
+#define MVS16_DMA_LATE 0   // LDS-DMA ring: 1: the barrier at the end of k-step p waits only for position p + 1 (s_waitcnt vmcnt(3): the three
+#endif                     //    requests of position p + 2, issued in k-step p, stay in flight for one more k-step); 0: vmcnt(0) - every k-step
+                           //    then ends behind its own weight request's L2 round trip.  Measured on the fp16 form (profiles/r03_ab_dma_late.log): 1 is 0.5 % SLOWER -
+                           //    the request has landed by the end of its k-step, and the A operands of row block 0 are better read a k-step early
 #ifndef MVS16_LDSDMA
 #define MVS16_LDSDMA 1     // 1: the weight stream reaches LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write);
 #endif                     // 0: through registers (three dwordx4 loads per thread and k-step, stored one k-step later)
@@ -278,7 +283,8 @@ __device__ __forceinline__ const f32x4* ring16_nxt(const Ring16& r) { return r.b
 
 template <bool kDma>
 __device__ __forceinline__ void ring16_next(Ring16& r) {
-    if (kDma) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kDma && MVS16_DMA_LATE) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (kDma) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     r.c = r.c + 1 == kR16Slots ? 0 : r.c + 1;
     r.p = r.p + 1 == r.P ? 0 : r.p + 1;
@@ -323,6 +329,11 @@ __device__ __forceinline__ void kstep16(Ring16& ring, int lane, int g, const B16
     const f32x4* cur = ring16_cur(ring) + lane;
     const f32x4* nxt = ring16_nxt(ring) + lane;
     u32x4 a[3] = {ring.a0[0], ring.a0[1], ring.a0[2]};
+    if (kDma && MVS16_DMA_LATE) {
+        // position p + 1 is published only by the barrier that ends k-step p: row block 0's A chunks are read here, not one k-step early
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[q] = __builtin_bit_cast(u32x4, cur[q * 64]);
+    }
     f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
     // the lane's part of perm_f4, formed HERE (behind an empty asm): left to itself the compiler hoists the eight row addresses of every
     // layer's bias vector out of the tile loop and spills them
@@ -333,7 +344,9 @@ __device__ __forceinline__ void kstep16(Ring16& ring, int lane, int g, const B16
     for (int rb = 0; rb < 8; ++rb) {
         u32x4 an[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) an[q] = __builtin_bit_cast(u32x4, rb < 7 ? cur[((rb + 1) * 3 + q) * 64] : nxt[q * 64]);
+        for (int q = 0; q < 3; ++q)
+            if (rb < 7 || !(kDma && MVS16_DMA_LATE)) an[q] = __builtin_bit_cast(u32x4, rb < 7 ? cur[((rb + 1) * 3 + q) * 64] : nxt[q * 64]);
+            else an[q] = a[q];
         if (kMode == 1) cut_pair<kRelu>(nv[rb >> 2][2 * (rb & 3)], nv[rb >> 2][2 * (rb & 3) + 1], rb & 3, bn[rb >> 2]);
         if (kMode == 2) {
             if (rb >= 1 && rb <= 4) {              // pair q = rb - 1 of both column blocks: q < 2 from acc[0], q >= 2 from acc[1]
@@ -979,6 +992,7 @@ __global__ __launch_bounds__(512, 2) void MVS16_KERNEL(FieldParams p, const f32x
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // weight requests still in flight must land before the LDS is released
 }
 
 }  // namespace

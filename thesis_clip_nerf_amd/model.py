@@ -249,7 +249,9 @@ class MVVNeRFRenderer:
         pc, pf = self.packed()
         if self._packed_bwd is None:
             self._packed_bwd = (ops.pack_bwd_streams(self.coarse_net), ops.pack_bwd_streams(self.fine_net))
-        split = self.packed_split() if self.f32_gemm != 'mfma_f32' else None      # the training forward always takes an exact-cut kernel
+        split = self.packed_split() if self.f32_gemm != 'mfma_f32' else None
+        if split is not None:
+            ops.set_split_kernel(self.f32_gemm)          # the training forward runs on the same split kernel as inference; the backward keeps the exact cut
         use_tables = ops.texel_table_pays(r, self.n_samples, h, w)      # layer 0's feature rows per texel
         tb = self._train_bufs
         key = (b, v, r, h, w, bool(return_d_features))
