@@ -149,7 +149,7 @@ __device__ __forceinline__ void cut_pair(float v0, float v1, int q, B16& b) {
 #if MVS16_F16
     // p1 = B0 = rn16(v / 64), p3 = B1 = rn16(64 (v / 64 - B0)) = rn16(v - 64 B0): the remainder is exact in fp32, formed by one
     // mixed-precision fma per value (v_fma_mix_f32 reads B0's halves as they lie); p2 is not used
-    const f32x2 t = {v0 * 0.015625f, v1 * 0.015625f};
+    const f32x2 t = {v0 * 0.015625f, v1 * 0.015625f};     // (forced into one v_pk_mul_f32 by inline asm: 2 % slower - the scheduler no longer places it)
     const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t, f16x2));
     float r0, r1;
     asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "s"(-64.0f), "v"(v0));
@@ -284,7 +284,11 @@ __device__ __forceinline__ const f32x4* ring16_nxt(const Ring16& r) { return r.b
 template <bool kDma>
 __device__ __forceinline__ void ring16_next(Ring16& r) {
     if (kDma && MVS16_DMA_LATE) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef MVS16_ABL_BARRIER
+    else if (kDma) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // timing-only ablation (races): no workgroup barrier per k-step
+#else
     else if (kDma) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     r.c = r.c + 1 == kR16Slots ? 0 : r.c + 1;
     r.p = r.p + 1 == r.P ? 0 : r.p + 1;
@@ -344,10 +348,21 @@ __device__ __forceinline__ void kstep16(Ring16& ring, int lane, int g, const B16
     for (int rb = 0; rb < 8; ++rb) {
         u32x4 an[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < 3; ++q) {
+#ifdef MVS16_ABL_A0S
+            if (q == 1) continue;                                  // timing-only ablation (wrong results): the A0 / 64 piece is not read from LDS
+#endif
             if (rb < 7 || !(kDma && MVS16_DMA_LATE)) an[q] = __builtin_bit_cast(u32x4, rb < 7 ? cur[((rb + 1) * 3 + q) * 64] : nxt[q * 64]);
             else an[q] = a[q];
+        }
+#ifdef MVS16_ABL_A0S
+        an[1] = an[0];
+#endif
+#ifdef MVS16_ABL_CUT
+        if (kMode == 1 && rb == 0) { bn[0] = b[0]; bn[1] = b[1]; }            // timing-only ablation (wrong results): no operand cut in the k-steps
+#else
         if (kMode == 1) cut_pair<kRelu>(nv[rb >> 2][2 * (rb & 3)], nv[rb >> 2][2 * (rb & 3) + 1], rb & 3, bn[rb >> 2]);
+#endif
         if (kMode == 2) {
             if (rb >= 1 && rb <= 4) {              // pair q = rb - 1 of both column blocks: q < 2 from acc[0], q >= 2 from acc[1]
                 const int q = rb - 1;
@@ -694,9 +709,13 @@ __global__ __launch_bounds__(512, 2) void MVS16_KERNEL(FieldParams p, const f32x
                     const float a1 = (gl < 3 ? cd : cam[1]) * 3.14159274101257324f;
                     const float a2 = cam[2] * 3.14159274101257324f;
                     float s0, c0, s1, c1, s2, c2;
+#ifdef MVS16_ABL_SINCOS
+                    s0 = a0; c0 = a1; s1 = a2; c1 = a0; s2 = a1; c2 = a2;        // timing-only ablation (wrong results): no accurate sin / cos
+#else
                     sincos_f32(a0 * (gl < 3 ? 1.0f : 256.0f), &s0, &c0);
                     sincos_f32(a1 * (gl < 3 ? 32.0f : 256.0f), &s1, &c1);
                     sincos_f32(a2 * 256.0f, &s2, &c2);
+#endif
                     auto dbl = [](float& sk, float& ck) {
                         const float t2 = sk + sk;
                         const float cn = fmaf(-t2, sk, 1.0f);              // cos 2t = 1 - 2 sin^2 t
@@ -763,7 +782,11 @@ __global__ __launch_bounds__(512, 2) void MVS16_KERNEL(FieldParams p, const f32x
             // rows [h][nb][16] (pass P = floats h*64 + P*32 + {0..31}), lerped rows ADD into the accumulators; direct: 4 passes
             // of 64 raw channels, the lerped rows are the B operands of 2 k-steps each.
 #pragma unroll
+#ifdef MVS16_ABL_GATHER
+            for (int P = 0; P < 0; ++P) {                                        // timing-only ablation (wrong results): no table / feature gather
+#else
             for (int P = 0; P < (kProj ? 2 : 4); ++P) {
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const f32x4* tbase = kProj ? reinterpret_cast<const f32x4*>(p.texel_table) + (nl >> 3) * 16 + (nl & 7) + P * 8
                                            : reinterpret_cast<const f32x4*>(p.features) + P * 16 + nl;
