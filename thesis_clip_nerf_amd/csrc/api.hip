@@ -413,12 +413,16 @@ size_t mvnerf_stash_bytes(int B, int V, int R, int S) {
 // Per-workgroup partials of a weight-gradient span, summed in workgroup order by reduce_partials_kernel.  The three users:
 // dw0_split8_kernel (layer 0: 379 x 128 + 128 floats per workgroup, kBwdMaxWGs / 2 = 256 workgroups at most, never more than there are
 // view tiles), dense_bwd_split8_kernel (128 x 128 + 128, kFusedBwdWGs / 2) and the read-out's dw_tile_kernel (516 floats, kBwdMaxWGs).
-static size_t partial_floats(long n_tiles, int V) {
+// Behind them: 14 x 64 floats, max |g| of the gradient tensor each layer launch of the training backward reads (the power-of-two scale
+// of its fp16 cut; train_ops.hip, MVT_BWD_F16).
+constexpr int kAmaxTensors = 14;
+static size_t partial_only_floats(long n_tiles, int V) {
     const long wg0 = n_tiles * V < kBwdMaxWGs / 2 ? n_tiles * V : kBwdMaxWGs / 2;
     const long wgr = n_tiles < kBwdMaxWGs ? n_tiles : kBwdMaxWGs;
     const size_t a = (size_t)wg0 * (mvnerf::kIn * mvnerf::kHidden + mvnerf::kHidden), b = (size_t)wgr * 516;
-    return a > b ? a : b;
+    return ((a > b ? a : b) + 3) & ~(size_t)3;
 }
+static size_t partial_floats(long n_tiles, int V) { return partial_only_floats(n_tiles, V) + (size_t)kAmaxTensors * mvnerf::kBwdAmaxSlots; }
 std::atomic<int> g_deterministic{0};
 
 size_t mvnerf_field_backward_scratch_bytes(int B, int V, int R, int S) {
@@ -565,8 +569,13 @@ int mvnerf_field_backward_table(const float* rays_o, const float* rays_d, const 
     auto fused_slot = [&](int m) { return stash + 7 * vslot + (size_t)m * fslot; };      // mean,h4,x4,h5,x5,h6,x6
     hipError_t e;
 #define MV_TRY(call) if ((e = (call)) != hipSuccess) return hip_status(e, "mvnerf_field_backward")
+    // max |g| slots of the 13 gradient tensors of the chain (zeroed here, filled by each tensor's producer)
+    float* amax = part + partial_only_floats(n_tiles, V);
+    MV_TRY(mvnerf::launch_zero(amax, (size_t)kAmaxTensors * mvnerf::kBwdAmaxSlots * sizeof(float), st));
+    int am = 0;                                        // amax + 64 am belongs to buf[g]
+    auto amax_of = [&](int k) { return amax + (size_t)k * mvnerf::kBwdAmaxSlots; };
     // read-out
-    MV_TRY(launch_readout_bwd(fused_slot(6), rgbs, d_rgbs, net_keras + kKerasWr, total, n_tiles, do_tl, buf[0], st));
+    MV_TRY(launch_readout_bwd(fused_slot(6), rgbs, d_rgbs, net_keras + kKerasWr, total, n_tiles, do_tl, buf[0], st, amax_of(0)));
     MV_TRY(launch_dw_tile(fused_slot(6), 1, do_tl, 32, n_tiles, grad + kKerasWr, 4, 4, grad + kKerasBr, kBwdMaxWGs, part, st));
     int g = 0;                                         // buf[g] holds dL/d(block output)
     for (int bi = 5; bi >= 0; --bi) {
@@ -583,10 +592,12 @@ int mvnerf_field_backward_table(const float* rays_o, const float* rays_d, const 
         const int dh = (g + 1) % 3, gn = (g + 2) % 3;
         // second Dense of the block: out = x_in + W2^T relu(hid) + b2      (dX and dW in one pass over the tiles)
         MV_TRY(launch_dense_bwd_fused(buf[g], pre_hid, bwd_streams + (size_t)(2 * bi + 1) * kHiddenWFloats, nullptr, buf[dh], nt,
-                                      gb + kHidden * kHidden + kHidden, gb + 2 * kHidden * kHidden + kHidden, kFusedBwdWGs, part, st));
+                                      gb + kHidden * kHidden + kHidden, gb + 2 * kHidden * kHidden + kHidden, kFusedBwdWGs, part, st,
+                                      amax_of(am), amax_of(am + 1)));
         // first Dense: hid = W1^T relu(x_in) + b1 ; the identity branch adds dL/d(out) back
         MV_TRY(launch_dense_bwd_fused(buf[dh], pre_in, bwd_streams + (size_t)(2 * bi) * kHiddenWFloats, buf[g], buf[gn], nt, gb,
-                                      gb + kHidden * kHidden, kFusedBwdWGs, part, st));
+                                      gb + kHidden * kHidden, kFusedBwdWGs, part, st, amax_of(am + 1), amax_of(am + 2)));
+        am += 2;                                       // (the view broadcast scales by 1 / V: its output keeps its input's bound)
         g = gn;
     }
     // layer 0 (inputs recomputed)

@@ -131,14 +131,18 @@ hipError_t launch_rows_to_tl(const float* rows, long n_rows, long n_tiles, int a
 hipError_t launch_dw_tile(const float* a_tl, int relu_a, const float* g_tl, int g_feats, long n_tiles, float* dW, int ldn,
                           int n_valid, float* db, int max_wgs, float* part, hipStream_t st);
 hipError_t launch_dense_bwd_fused(const float* g_tl, const float* a_tl, const float* wstream, const float* resid_tl,
-                                  float* da_tl, long n_tiles, float* dW, float* db, int max_wgs, float* part, hipStream_t st);
+                                  float* da_tl, long n_tiles, float* dW, float* db, int max_wgs, float* part, hipStream_t st,
+                                  const float* amax_in = nullptr, float* amax_out = nullptr);
+// amax_in / amax_out (training form): 64-float slots holding max |g| of the incoming / outgoing gradient tensor (zeroed by the caller before
+// the producer runs): the power-of-two scale of the fp16 cut of G (train_ops.hip, MVT_BWD_F16)
+constexpr int kBwdAmaxSlots = 64;
 hipError_t launch_mse_grad(const float* pred, const float* label, long n, float* d_pred, float* loss, hipStream_t st);
 hipError_t launch_composite_bwd(const float* z, const float* rgbs, const float* d_rgb, const float* d_depth,
                                 const float* d_w, int n_rays, int S, float* d_rgbs, float* d_z, hipStream_t st);
 hipError_t launch_resample_bwd(const float* z, const float* weights, const float* u_fine, const int32_t* fine_rank,
                                const float* d_z_all, int n_rays, int q7_mode, float* d_weights, hipStream_t st);
 hipError_t launch_readout_bwd(const float* x_tl, const float* rgbs, const float* d_rgbs, const float* wr, long n_rows,
-                              long n_tiles, float* do_tl, float* g_tl, hipStream_t st);
+                              long n_tiles, float* do_tl, float* g_tl, hipStream_t st, float* amax_out = nullptr);
 hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, float* db0, int max_wgs, float* part, hipStream_t st);
 hipError_t launch_view_broadcast(const float* g_fused, int V, long tiles_per_b, long n_tiles, float* g_view, hipStream_t st);
 hipError_t launch_adam_clip(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1, float beta2,

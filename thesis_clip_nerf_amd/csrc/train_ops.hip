@@ -234,6 +234,88 @@ __device__ __forceinline__ void cut3(const f32x4& lo, const f32x4& hi, u32x4_t& 
     }
 }
 
+#ifndef MVT_BWD_F16
+#define MVT_BWD_F16 1      // dense_bwd_split8_kernel: 1: both GEMMs as three fp16 MFMAs per product on two-piece operands (the scheme of
+#endif                     //    field_eval_split16_impl.h; the gradient tile is scaled by a power of two taken from the producer's max |g|);
+                           //    0: six bf16 MFMAs on exactly cut three-piece operands (round 2)
+using f16x8_t = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2_t = __attribute__((ext_vector_type(2))) _Float16;
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
+
+__device__ __forceinline__ f32x16 mfma16h(u32x4_t a, u32x4_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+// 8 fp32 values x (two float4) -> two fp16 pieces of t = x * s_lo: hi = rn16(t), lo = rn16(64 (t - hi)) = rn16(x * s_hi - 64 hi) with
+// s_hi = 64 s_lo (both powers of two: the remainder is exact in fp32).  kRelu: relu first.  The partner of `lo` carries a factor 1/64.
+template <bool kRelu>
+__device__ __forceinline__ void cut2h_scaled(const f32x4& xlo, const f32x4& xhi, float s_lo, float s_hi, u32x4_t& hi, u32x4_t& lo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v0 = q < 2 ? xlo[2 * q] : xhi[2 * q - 4], v1 = q < 2 ? xlo[2 * q + 1] : xhi[2 * q - 3];
+        if (kRelu) {
+            const int i0 = __builtin_bit_cast(int, v0), i1 = __builtin_bit_cast(int, v1);
+            v0 = __builtin_bit_cast(float, i0 > 0 ? i0 : 0);
+            v1 = __builtin_bit_cast(float, i1 > 0 ? i1 : 0);
+        }
+        const f32x2_t t = {v0 * s_lo, v1 * s_lo};
+        const float u0 = v0 * s_hi, u1 = v1 * s_hi;
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t, f16x2_t));
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "s"(-64.0f), "v"(u0));
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "s"(-64.0f), "v"(u1));
+        const f32x2_t r = {r0, r1};
+        hi[q] = h;
+        lo[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
+    }
+}
+
+// 8 fp32 values -> the three fp16 pieces of an A operand with t = 64 x: a0 = rn16(t), a0s = a0 / 64, a1 = rn16(t - a0) (unscaled remainder)
+template <bool kRelu>
+__device__ __forceinline__ void cut3a(const f32x4& xlo, const f32x4& xhi, u32x4_t& a0, u32x4_t& a0s, u32x4_t& a1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v0 = q < 2 ? xlo[2 * q] : xhi[2 * q - 4], v1 = q < 2 ? xlo[2 * q + 1] : xhi[2 * q - 3];
+        if (kRelu) {
+            const int i0 = __builtin_bit_cast(int, v0), i1 = __builtin_bit_cast(int, v1);
+            v0 = __builtin_bit_cast(float, i0 > 0 ? i0 : 0);
+            v1 = __builtin_bit_cast(float, i1 > 0 ? i1 : 0);
+        }
+        const float t0 = v0 * 64.0f, t1 = v1 * 64.0f;
+        const f32x2_t t = {t0, t1};
+        const f16x2_t h = __builtin_convertvector(t, f16x2_t);
+        const unsigned hb = __builtin_bit_cast(unsigned, h);
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "s"(-1.0f), "v"(t0));
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "s"(-1.0f), "v"(t1));
+        const f32x2_t r = {r0, r1};
+        const f16x2_t k64 = {(_Float16)0.015625f, (_Float16)0.015625f};
+        a0[q] = hb;
+        a0s[q] = __builtin_bit_cast(unsigned, h * k64);
+        a1[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
+    }
+}
+
+// max |g| of a gradient tensor travels beside it in 64 slots (the producers' workgroups spread their atomics over them): the power of two
+// that brings it to [2^13, 2^14), as (2^e, 2^-e)
+constexpr int kAmaxSlots = 64;
+__device__ __forceinline__ void amax_scale(const float* __restrict__ amax, int lane, float* sc, float* inv) {
+    float m = amax ? amax[lane] : 0.0f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    const int ex = (__builtin_bit_cast(int, m) >> 23) & 0xff;                 // biased exponent of the maximum (0: all gradients zero)
+    int e = ex == 0 ? 0 : 140 - ex;                                           // m 2^e in [2^13, 2^14)
+    e = e > 120 ? 120 : (e < -100 ? -100 : e);
+    e = __builtin_amdgcn_readfirstlane(e);
+    *sc = __builtin_bit_cast(float, (127 + e) << 23);
+    *inv = __builtin_bit_cast(float, (127 - e) << 23);
+}
+__device__ __forceinline__ void amax_publish(float* __restrict__ amax, float m) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (amax && (threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(amax) + (blockIdx.x & (kAmaxSlots - 1)), __builtin_bit_cast(int, m));
+}
+
 #ifndef MVT_STAMP
 #define MVT_STAMP 0        // scripts/bwd_probe.hip: per-wave cycle totals of the phases of a tile (dense_bwd_split8_kernel)
 #endif
@@ -379,12 +461,21 @@ constexpr int kBwd8LdsBytes = (kBwd8Pcol + 1536) * 16;                          
 
 __global__ __launch_bounds__(512, 1) void dense_bwd_split8_kernel(
     const float* __restrict__ g_tl, const float* __restrict__ a_tl, const float* __restrict__ wstream, const float* __restrict__ resid_tl,
-    float* __restrict__ da_tl, long n_tiles, float* __restrict__ dW, float* __restrict__ db, long part_stride) {
+    float* __restrict__ da_tl, long n_tiles, float* __restrict__ dW, float* __restrict__ db, long part_stride,
+    const float* __restrict__ amax_in, float* __restrict__ amax_out) {
     extern __shared__ __attribute__((aligned(16))) f32x4 sbuf[];
     using gptr = const __attribute__((address_space(1))) void*;
     using lptr = __attribute__((address_space(3))) void*;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, i = lane & 31;
     const int v = __builtin_amdgcn_readfirstlane(tid >> 6);                  // wave 0..7
+#if MVT_BWD_F16
+    // G is cut as g 2^e / 64 (+ remainder x 64): 2^e from the producer's max |g|, so that the pieces stay normal fp16 numbers whatever the
+    // loss scale; dL/da and dW come out scaled by 2^e and are multiplied by 2^-e where they leave the registers
+    float g_sc, g_inv;
+    amax_scale(amax_in, lane, &g_sc, &g_inv);
+    const float g_sc_lo = g_sc * 0.015625f;
+    float out_max = 0.0f;
+#endif
     const float* sF = reinterpret_cast<const float*>(sbuf);
     u32x4_t* sP = reinterpret_cast<u32x4_t*>(sbuf);
     const int n_tiles32 = (int)n_tiles, stride = (int)gridDim.x;
@@ -430,17 +521,28 @@ __global__ __launch_bounds__(512, 1) void dense_bwd_split8_kernel(
             chi[q] = sF[buf * 4 * kBwd8Raw + colf[4 + q]];
         }
         u32x4_t p0, p1, p2;
-        cut3<false>(lo, hi, p0, p1, p2);
         u32x4_t* pr = sP + kBwd8Prow + (v * 3) * 64 + lane;                 // chunk (ks, nb) = v
+        u32x4_t* pc = sP + kBwd8Pcol + (v * 3) * 64 + lane;                 // chunk ks = v
+#if MVT_BWD_F16
+        cut2h_scaled<false>(lo, hi, g_sc_lo, g_sc, p0, p1);                 // pieces 0 (hi) and 1 (lo x 64); slot 2 of a chunk stays unused
+        pr[0] = p0;
+        pr[64] = p1;
+        dbv = sum8(lo, hi, dbv);
+        cut2h_scaled<false>(clo, chi, g_sc_lo, g_sc, p0, p1);
+        pc[0] = p0;
+        pc[64] = p1;
+        (void)p2;
+#else
+        cut3<false>(lo, hi, p0, p1, p2);
         pr[0] = p0;
         pr[64] = p1;
         pr[128] = p2;
         dbv = sum8(lo, hi, dbv);
         cut3<false>(clo, chi, p0, p1, p2);
-        u32x4_t* pc = sP + kBwd8Pcol + (v * 3) * 64 + lane;                 // chunk ks = v
         pc[0] = p0;
         pc[64] = p1;
         pc[128] = p2;
+#endif
         return dbv;
     };
     float dbacc = 0.0f;
@@ -469,7 +571,11 @@ __global__ __launch_bounds__(512, 1) void dense_bwd_split8_kernel(
                     lo[e] = h ? recv : g0[e];               // h = 0: n = 16ks + e (own g0);        h = 1: n = 16ks + 8 + e (partner's g1)
                     hi[e] = h ? g1[e] : recv;               // h = 0: n = 16ks + 4 + e (partner's g0); h = 1: n = 16ks + 12 + e (own g1)
                 }
+#if MVT_BWD_F16
+                cut3a<false>(lo, hi, wp[ks][0], wp[ks][1], wp[ks][2]);          // (64 w, 64 w / 64, remainder)
+#else
                 cut3<false>(lo, hi, wp[ks][0], wp[ks][1], wp[ks][2]);
+#endif
             }
         }
         int eidx[4];
@@ -509,6 +615,24 @@ __global__ __launch_bounds__(512, 1) void dense_bwd_split8_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             const u32x4_t* pc = sP + kBwd8Pcol + lane;
+#if MVT_BWD_F16
+            u32x4_t b[2] = {pc[0], pc[64]};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                u32x4_t bn[2];
+                if (ks < 7) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) bn[q] = pc[((ks + 1) * 3 + q) * 64];
+                }
+                acc = mfma16h(wp[ks][1], b[1], acc);            // (64 w / 64) x (64 remainder of g)
+                acc = mfma16h(wp[ks][2], b[0], acc);            // remainder of 64 w x g hi
+                acc = mfma16h(wp[ks][0], b[0], acc);
+                if (ks < 7) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) b[q] = bn[q];
+                }
+            }
+#else
             u32x4_t b[3] = {pc[0], pc[64], pc[128]};
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
@@ -528,6 +652,7 @@ __global__ __launch_bounds__(512, 1) void dense_bwd_split8_kernel(
                     for (int q = 0; q < 3; ++q) b[q] = bn[q];
                 }
             }
+#endif
             STAMP(3)
             // the residual rows and the next raw tile have landed (they had the cut and the MFMA section); the previous stores too
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -543,13 +668,22 @@ __global__ __launch_bounds__(512, 1) void dense_bwd_split8_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int ro = ((r & 3) + 8 * (r >> 2)) * 32;
                 const float av = sF[eidx[r & 3] + 8 * (r >> 2) * 32];
+#if MVT_BWD_F16
+                const float val = (av > 0.0f ? acc[r] * g_inv : 0.0f) + sR[ro];
+                out_max = fmaxf(out_max, fabsf(val));
+                *(__attribute__((address_space(1))) float*)(optr + 4 * ro + oo) = val;
+#else
                 const float val = av > 0.0f ? acc[r] : 0.0f;
                 *(__attribute__((address_space(1))) float*)(optr + 4 * ro + oo) = val + sR[ro];
+#endif
             }
             cur ^= 1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) eidx[e] ^= 4 * kBwd8Raw;
         }
+#if MVT_BWD_F16
+        amax_publish(amax_out, out_max);
+#endif
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");        // end: all MFMA sections done, the sample-packed image is free
         // bias gradient: rows 32 (v % 4) + i; this wave's samples [8h, 8h+8) of k-step 0 and, from wave v + 4, of k-step 1
         float* xch = reinterpret_cast<float*>(sbuf + kBwd8Prow);
@@ -586,9 +720,30 @@ __global__ __launch_bounds__(512, 1) void dense_bwd_split8_kernel(
             STAMP(2)
             // this wave's own A operand (rows 32u + i of relu(a)) is cut behind the barrier: nobody waits for it
             u32x4_t ap[2][3];
+            const u32x4_t* pr = sP + kBwd8Prow + lane;
+#if MVT_BWD_F16
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) cut3a<true>(sbuf[aidx[2 * ks]], sbuf[aidx[2 * ks + 1]], ap[ks][0], ap[ks][1], ap[ks][2]);
+            u32x4_t b[2] = {pr[0], pr[64]};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {                       // chunk c = (ks = c / 4, nb = c % 4)
+                u32x4_t bn[2];
+                if (c < 7) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) bn[q] = pr[((c + 1) * 3 + q) * 64];
+                }
+                const int ks = c >> 2, nb = c & 3;
+                dwacc[nb] = mfma16h(ap[ks][1], b[1], dwacc[nb]);
+                dwacc[nb] = mfma16h(ap[ks][2], b[0], dwacc[nb]);
+                dwacc[nb] = mfma16h(ap[ks][0], b[0], dwacc[nb]);
+                if (c < 7) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) b[q] = bn[q];
+                }
+            }
+#else
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) cut3<true>(sbuf[aidx[2 * ks]], sbuf[aidx[2 * ks + 1]], ap[ks][0], ap[ks][1], ap[ks][2]);
-            const u32x4_t* pr = sP + kBwd8Prow + lane;
             u32x4_t b[3] = {pr[0], pr[64], pr[128]};
 #pragma unroll
             for (int c = 0; c < 8; ++c) {                       // chunk c = (ks = c / 4, nb = c % 4)
@@ -609,6 +764,7 @@ __global__ __launch_bounds__(512, 1) void dense_bwd_split8_kernel(
                     for (int q = 0; q < 3; ++q) b[q] = bn[q];
                 }
             }
+#endif
             STAMP(3)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's part of the next raw tile has landed
             STAMP(4)
@@ -626,7 +782,11 @@ __global__ __launch_bounds__(512, 1) void dense_bwd_split8_kernel(
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
+#if MVT_BWD_F16
+            for (int r = 0; r < 16; ++r) grad_out(dWo + (long)(32 * u + acc_row(r, hh)) * kHidden + 32 * nb + col, dwacc[nb][r] * g_inv, store);
+#else
             for (int r = 0; r < 16; ++r) grad_out(dWo + (long)(32 * u + acc_row(r, hh)) * kHidden + 32 * nb + col, dwacc[nb][r], store);
+#endif
     }
 #if MVT_STAMP
     if (lane == 0 && blockIdx.x < 256) {
@@ -639,7 +799,8 @@ __global__ __launch_bounds__(512, 1) void dense_bwd_split8_kernel(
 }
 
 hipError_t launch_dense_bwd_fused(const float* g_tl, const float* a_tl, const float* wstream, const float* resid_tl,
-                                  float* da_tl, long n_tiles, float* dW, float* db, int max_wgs, float* part, hipStream_t st) {
+                                  float* da_tl, long n_tiles, float* dW, float* db, int max_wgs, float* part, hipStream_t st,
+                                  const float* amax_in, float* amax_out) {
     // `part` != nullptr (deterministic mode): every workgroup stores its partial of the span [dW | db] (db directly behind dW) and
     // launch_reduce_partials adds them in a fixed order; otherwise fp32 atomics straight onto the gradient.
     static std::atomic<bool> attr_done[16];               // first call per device sets the dynamic-LDS limits (idempotent)
@@ -661,10 +822,11 @@ hipError_t launch_dense_bwd_fused(const float* g_tl, const float* a_tl, const fl
         return hipGetLastError();
     }
     if (part && db != dW + kHidden * kHidden) return hipErrorInvalidValue;
+    if (MVT_BWD_F16 && !amax_in) return hipErrorInvalidValue;                               // the fp16 products need the gradient's scale
     const int span = kHidden * kHidden + kHidden;
     const unsigned wgs8 = (unsigned)(n_tiles < max_wgs / 2 ? n_tiles : max_wgs / 2);       // one 512-thread workgroup per CU
     hipLaunchKernelGGL(dense_bwd_split8_kernel, dim3(wgs8), dim3(512), kBwd8LdsBytes, st, g_tl, a_tl, wstream, resid_tl, da_tl, n_tiles,
-                       part ? part : dW, part ? part + kHidden * kHidden : db, part ? (long)span : 0L);
+                       part ? part : dW, part ? part + kHidden * kHidden : db, part ? (long)span : 0L, amax_in, amax_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !part) return e;
     return launch_reduce_partials(part, span, (int)wgs8, span, dW, st);
@@ -901,10 +1063,11 @@ hipError_t launch_resample_bwd(const float* z, const float* weights, const float
 __global__ __launch_bounds__(256) void readout_bwd_kernel(const float* __restrict__ x_tl, const float* __restrict__ rgbs,
                                                           const float* __restrict__ d_rgbs, const float* __restrict__ wr,
                                                           long n_rows, long n_tiles, float* __restrict__ do_tl,
-                                                          float* __restrict__ g_tl) {
+                                                          float* __restrict__ g_tl, float* __restrict__ amax_out) {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= n_tiles) return;
+    if (tile >= n_tiles) return;                           // (whole waves: a tile is a wave)
+    float out_max = 0.0f;
     const long row = tile * 32 + j;
     float dov[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (row < n_rows) {
@@ -924,8 +1087,11 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(const float* __restric
         g = fmaf(w4[1], dov[1], g);
         g = fmaf(w4[2], dov[2], g);
         g = fmaf(w4[3], dov[3], g);
-        g_tl[o] = x_tl[o] > 0.0f ? g : 0.0f;
+        const float gv = x_tl[o] > 0.0f ? g : 0.0f;
+        out_max = fmaxf(out_max, fabsf(gv));
+        g_tl[o] = gv;
     }
+    amax_publish(amax_out, out_max);                       // max |g| for the fp16 cut of the first layer launch (dense_bwd_split8_kernel)
 }
 
 __global__ void zero_kernel(unsigned* __restrict__ p, size_t n) {
@@ -943,11 +1109,11 @@ hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t st) {
 }
 
 hipError_t launch_readout_bwd(const float* x_tl, const float* rgbs, const float* d_rgbs, const float* wr, long n_rows,
-                              long n_tiles, float* do_tl, float* g_tl, hipStream_t st) {
+                              long n_tiles, float* do_tl, float* g_tl, hipStream_t st, float* amax_out) {
     hipError_t e = launch_zero(do_tl, (size_t)n_tiles * 32 * 32 * sizeof(float), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(readout_bwd_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, x_tl, rgbs, d_rgbs, wr,
-                       n_rows, n_tiles, do_tl, g_tl);
+                       n_rows, n_tiles, do_tl, g_tl, amax_out);
     return hipGetLastError();
 }
 
