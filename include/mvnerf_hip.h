@@ -162,8 +162,8 @@ int mvnerf_field_eval_bf16maps(const float* rays_o, const float* rays_d, const f
  *   MVNERF_SPLIT_BF16X6           three bf16 pieces per operand, an EXACT cut, the six products of order >= 2^-16 as
  *                                 v_mfma_f32_16x16x32_bf16; dropped terms <= 2^-24 relative; full fp32 range (field_eval_split16.hip)
  *   MVNERF_SPLIT_BF16X6_32        the same products as v_mfma_f32_32x32x16_bf16 (round 2's kernel, field_eval_split.hip)
- * The training forward (mvnerf_field_eval_stash_split) follows the same choice (the 32x32x16 kernel has no fp16 form: it and the backward
- * keep the exact cut). ---- */
+ * The training forward (mvnerf_field_eval_stash_split) follows the same choice (the 32x32x16 kernel has no fp16 form); the backward's layer
+ * launches always use fp16 two-piece products with a per-tensor power-of-two scale on the gradients (csrc/train_ops.hip, MVT_BWD_F16). ---- */
 #define MVNERF_SPLIT_F16X3 0
 #define MVNERF_SPLIT_BF16X6 1
 #define MVNERF_SPLIT_BF16X6_32 2

@@ -1,6 +1,6 @@
 // Backward pass of the render path (MVVNeRFRenderer.train_step, model_v0.py:186-197) for gfx950.
 //
-// Layer-major: the forward pass (field_eval_split_kernel<.., kStash=true>) leaves the 13 pre-activation tensors
+// Layer-major: the forward pass (field_eval_split16[h]_kernel<.., kStash=true>) leaves the 13 pre-activation tensors
 // of the trunk in HBM in tile layout (mvnerf_mfma.h); each Dense layer's backward is then one pass
 // over all 32-sample tiles, dense_bwd_split8_kernel:
 //   dX = (W . G) (.) [pre > 0] (+ residual)   -- the forward's weight-stream MFMA code fed with transposed kernels
