@@ -25,11 +25,11 @@
 //   MVS16_F16 = 1  operands as TWO fp16 pieces, three v_mfma_f32_16x16x32_f16 per product block.  With tw = 64 w and tv = v / 64 (powers
 //                  of two: exact, tw tv = w v):  A0 = rn16(tw), A1 = rn16(tw - A0), A0s = A0 / 64;  B0 = rn16(tv), B1 = rn16(64 (tv - B0))
 //                  = rn16(v - 64 B0);  acc += A0s B1 + A1 B0 + A0 B0.  Both remainders are exact in fp32 before they are rounded, so each
-//                  operand is represented to 22-24 significant bits (|error| <= 2^-23 |x|); the one dropped cross term (tw - A0)(tv - B0)
-//                  is <= 2^-22 |w v| (2^-25 typical).  The activation's remainder is scaled by 64 (and meets A0 / 64) so that it stays a
-//                  normal fp16 number down to |v| = 2^-3; below that, and for the weights' unscaled remainder below |w| = 2^-9, the
-//                  pieces go subnormal - the MFMA honours fp16 subnormals (scripts/f16_mfma_probe.hip) - with absolute errors <= 2^-25 |w|
-//                  resp. 2^-31 |v| per product.  Measured per ResNet block against float64: at or below the fp32 MFMA kernel's error
+//                  operand is represented to |error| <= 2^-23 |x| + a subnormal floor (2^-31 for a weight, 2^-25 for an activation:
+//                  tests/test_f16_split_math.py); the one dropped cross term (tw - A0)(tv - B0) is <= 2^-22 |w v| (2^-25 typical).  The
+//                  activation's remainder is scaled by 64 (and meets A0 / 64): its pieces keep all 11 bits for |v| >= 1/4, the weights'
+//                  unscaled remainder for |w| >= 2^-8; below that they go subnormal - the MFMA honours fp16 subnormals
+//                  (scripts/f16_mfma_probe.hip) - with absolute errors <= 2^-25 |w| resp. 2^-31 |v| per product.  Measured per ResNet block against float64: at or below the fp32 MFMA kernel's error
 //                  (tests/test_gpu_split.py).  Same stream size (three 1 KiB weight pieces per row block), two instead of three operand
 //                  pieces in registers, half the MFMAs.  Range: |w| < 1023, |v| < 4.19e6 (fp16 overflow beyond; the bf16 form has the full
 //                  fp32 range).
