@@ -607,7 +607,7 @@ int mvnerf_field_backward_table(const float* rays_o, const float* rays_d, const 
     p.B = B; p.V = V; p.R = R; p.S = S; p.H = H; p.W = W; p.total = total; p.n_tiles = n_tiles;
     p.texel_table = texel_table;                           // only the sample-position gradient uses it (launch_field_dz)
     p.net = net_keras;                                     // (Keras layout here: field_dz_table_kernel reads W0's rgb rows from it)
-    MV_TRY(launch_dw0(p, buf[g], grad + kKerasW0, grad + kKerasB0, kBwdMaxWGs, part, st));
+    MV_TRY(launch_dw0(p, buf[g], grad + kKerasW0, grad + kKerasB0, kBwdMaxWGs, part, st, amax_of(am)));
     // d_features through the texel table (texel_grad given): the samples' g0 is scattered onto the 128-channel table gradient and W0 is
     // applied once per texel afterwards; the sample-position gradient then takes the table path as well
     const bool via_table = d_features && texel_table && texel_grad;

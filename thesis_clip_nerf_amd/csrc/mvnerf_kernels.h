@@ -143,7 +143,8 @@ hipError_t launch_resample_bwd(const float* z, const float* weights, const float
                                const float* d_z_all, int n_rays, int q7_mode, float* d_weights, hipStream_t st);
 hipError_t launch_readout_bwd(const float* x_tl, const float* rgbs, const float* d_rgbs, const float* wr, long n_rows,
                               long n_tiles, float* do_tl, float* g_tl, hipStream_t st, float* amax_out = nullptr);
-hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, float* db0, int max_wgs, float* part, hipStream_t st);
+hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, float* db0, int max_wgs, float* part, hipStream_t st,
+                      const float* amax_in = nullptr);
 hipError_t launch_view_broadcast(const float* g_fused, int V, long tiles_per_b, long n_tiles, float* g_view, hipStream_t st);
 hipError_t launch_adam_clip(float* param, const float* grad, float* m, float* v, long n, float lr_t, float beta1, float beta2,
                             float eps, float clip, const unsigned char* update_mask, hipStream_t st);

@@ -1231,7 +1231,7 @@ constexpr int kDw8LdsBytes = (kDw8GeomQ + 2 * 32) * 16;
 #define MVT_DW0_ABL 0      // timing-only ablations (wrong results), bits: 1 no feature gathers, 2 no PE / rgb / geometry, 4 no MFMAs, 8 no build
 #endif
 __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const float* __restrict__ g0_tl, float* __restrict__ dW0,
-                                                            float* __restrict__ db0, long part_stride) {
+                                                            float* __restrict__ db0, long part_stride, const float* __restrict__ amax_in) {
     extern __shared__ __attribute__((aligned(16))) f32x4 sbuf[];
     using gptr = const __attribute__((address_space(1))) void*;
     using lptr = __attribute__((address_space(3))) void*;
@@ -1242,6 +1242,16 @@ __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const
     SampleGeom* geom = reinterpret_cast<SampleGeom*>(sbuf + kDw8Geom);          // [2][32]
     GeomQ* geomq = reinterpret_cast<GeomQ*>(sbuf + kDw8GeomQ);                  // [2][32]
     const int view_tiles = (int)(p.n_tiles * p.V), stride = (int)gridDim.x;
+#if MVT_BWD_F16
+    // fp16 two-piece products as in dense_bwd_split8_kernel: the inputs as (rn16(x / 64), rn16(x - 64 hi)), the gradient as the three
+    // pieces of 64 (g 2^e / 64) with 2^e from the tensor's max |g|; the accumulators carry a factor 2^e / 64, taken out at the store
+    float g_sc, g_inv;
+    amax_scale(amax_in, lane, &g_sc, &g_inv);
+    const float g_pre = g_sc * 0.015625f, out_scale = g_inv * 64.0f;
+#else
+    const float out_scale = 1.0f;
+    (void)amax_in;
+#endif
     auto sum8 = [](const f32x4& lo, const f32x4& hi, float accv) {
         float s = lo[0];
         const float t[7] = {lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -1356,11 +1366,18 @@ __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const
                 else hi[q - 4] = val;
             }
             u32x4_t p0, p1, p2;
-            cut3<false>(lo, hi, p0, p1, p2);
             u32x4_t* xa = sP + kDw8XA + ((kb * 2 + ps) * 3) * 64 + li;
+#if MVT_BWD_F16
+            cut2h_scaled<false>(lo, hi, 0.015625f, 1.0f, p0, p1);
+            xa[0] = p0;
+            xa[64] = p1;
+            (void)p2;
+#else
+            cut3<false>(lo, hi, p0, p1, p2);
             xa[0] = p0;
             xa[64] = p1;
             xa[128] = p2;
+#endif
         }
         // rows 0..122 from the PE + rgb table: thread = (row tid % 128, sample group tid / 128)
         {
@@ -1373,11 +1390,18 @@ __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const
                     hi[q] = pe_tab[(8 * sg + 4 + q) * kPe8Row + pr];
                 }
                 u32x4_t p0, p1, p2;
-                cut3<false>(lo, hi, p0, p1, p2);
                 u32x4_t* xa = sP + kDw8XA + (((pr >> 5) * 2 + (sg >> 1)) * 3) * 64 + (pr & 31) + 32 * (sg & 1);
+#if MVT_BWD_F16
+                cut2h_scaled<false>(lo, hi, 0.015625f, 1.0f, p0, p1);
+                xa[0] = p0;
+                xa[64] = p1;
+                (void)p2;
+#else
+                cut3<false>(lo, hi, p0, p1, p2);
                 xa[0] = p0;
                 xa[64] = p1;
                 xa[128] = p2;
+#endif
             }
         }
         // G: chunk (ks = v / 4, nb = v % 4) of the sample-packed image, and this wave's share of the bias gradient
@@ -1385,7 +1409,11 @@ __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const
             const f32x4 lo = sbuf[kDw8Raw + swz_f4(i, 4 * (v >> 2) + 2 * h) + 256 * (v & 3)];
             const f32x4 hi = sbuf[kDw8Raw + swz_f4(i, 4 * (v >> 2) + 2 * h + 1) + 256 * (v & 3)];
             u32x4_t p0, p1, p2;
+#if MVT_BWD_F16
+            cut3a<false>(lo * g_pre, hi * g_pre, p0, p1, p2);             // (64 t, 64 t / 64, remainder) of t = g 2^e / 64
+#else
             cut3<false>(lo, hi, p0, p1, p2);
+#endif
             u32x4_t* pb = sP + kDw8PB + (v * 3) * 64 + lane;
             pb[0] = p0;
             pb[64] = p1;
@@ -1441,6 +1469,12 @@ __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const
             for (int k = 0; k < 6; ++k)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
+#if MVT_BWD_F16
+                    const u32x4_t a0 = xa[((k * 2 + ks) * 3 + 0) * 64], a1 = xa[((k * 2 + ks) * 3 + 1) * 64];
+                    acc[k] = mfma16h(a1, b[ks][1], acc[k]);         // (64 remainder of x / 64) x (G0 / 64)
+                    acc[k] = mfma16h(a0, b[ks][2], acc[k]);         // x hi x remainder of G
+                    acc[k] = mfma16h(a0, b[ks][0], acc[k]);
+#else
                     const u32x4_t a0 = xa[((k * 2 + ks) * 3 + 0) * 64], a1 = xa[((k * 2 + ks) * 3 + 1) * 64], a2 = xa[((k * 2 + ks) * 3 + 2) * 64];
                     acc[k] = mfma16s(a2, b[ks][0], acc[k]);
                     acc[k] = mfma16s(a1, b[ks][1], acc[k]);
@@ -1448,6 +1482,7 @@ __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const
                     acc[k] = mfma16s(a1, b[ks][0], acc[k]);
                     acc[k] = mfma16s(a0, b[ks][1], acc[k]);
                     acc[k] = mfma16s(a0, b[ks][0], acc[k]);
+#endif
                 }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // taps and G of the next tile have landed
@@ -1473,11 +1508,13 @@ __global__ __launch_bounds__(512, 1) void dw0_split8_kernel(FieldParams p, const
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * (6 * (v >> 2) + k) + acc_row(r, hh);
-            if (row < kIn) grad_out(dW0 + (long)row * kHidden + 32 * nb + col, acc[k][r], store);
+            if (row < kIn) grad_out(dW0 + (long)row * kHidden + 32 * nb + col, acc[k][r] * out_scale, store);
         }
 }
 
-hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, float* db0, int max_wgs, float* part, hipStream_t st) {
+hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, float* db0, int max_wgs, float* part, hipStream_t st,
+                      const float* amax_in) {
+    if (MVT_BWD_F16 && !amax_in) return hipErrorInvalidValue;                  // the fp16 products need the gradient's scale
     const long view_tiles = p.n_tiles * p.V;
     if (view_tiles <= 0 || view_tiles > 0x7fffffffL) return hipErrorInvalidValue;
     static std::atomic<bool> attr_done[16];
@@ -1492,7 +1529,7 @@ hipError_t launch_dw0(const FieldParams& p, const float* g0_tl, float* dW0, floa
     if (!part || db0 != dW0 + kIn * kHidden) return hipErrorInvalidValue;      // one span [dW0 | db0], reduced from per-workgroup partials
     const int span = kIn * kHidden + kHidden;
     const unsigned wgs = (unsigned)(view_tiles < max_wgs / 2 ? view_tiles : max_wgs / 2);      // one 512-thread workgroup per CU
-    hipLaunchKernelGGL(dw0_split8_kernel, dim3(wgs), dim3(512), kDw8LdsBytes, st, p, g0_tl, part, part + kIn * kHidden, (long)span);
+    hipLaunchKernelGGL(dw0_split8_kernel, dim3(wgs), dim3(512), kDw8LdsBytes, st, p, g0_tl, part, part + kIn * kHidden, (long)span, amax_in);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_reduce_partials(part, span, (int)wgs, span, dW0, st);
