@@ -399,3 +399,34 @@ def test_c_abi_train_step_through_ctypes_only():
     assert L.mvnerf_pack_net(P(d['fine']), P(fresh), None) == 0
     torch.cuda.synchronize()
     assert torch.equal(fresh, packed[1])
+
+
+@pytest.mark.parametrize('views', [1, 2])
+def test_field_backward_is_equivariant_under_powers_of_two(views):
+    """The backward's fp16 products scale every gradient tensor by a power of two taken from its max |g| (train_ops.hip, MVT_BWD_F16):
+    multiplying the incoming cotangent by 2^k must multiply every weight gradient and dL/dz by 2^k bit for bit (powers of two commute with
+    every rounding in the chain, and the scale follows the tensor), whether the gradients sit at 1e-12 or at 1e+4 - and nothing may
+    overflow or flush on the way."""
+    sc = make_scene(seed=90 + views, batch=1, n_views=views, height=16, width=16, n_rays=64, bias_scale=0.05)
+    d = {k: dev(sc[k]) for k in ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'fine', 'u_coarse']}
+    z = ops.stratified_depths(d['u_coarse'], sc['near'], sc['far'])
+    packed, split, streams = ops.pack_net(d['fine']), ops.pack_net_split(d['fine']), ops.pack_bwd_streams(d['fine'])
+    geo = (d['rays_o'], d['rays_d'], z, d['images'], d['features'], d['intrinsics'], d['extrinsics_inv'])
+    rgbs, stash = ops.field_eval_stash(*geo, packed, packed_split=split)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    d_rgbs = torch.randn(rgbs.shape, device=DEV, generator=g)
+    out = {}
+    for k in (0, -40, 13):
+        grad = torch.zeros(247300, device=DEV)
+        d_z = torch.zeros_like(z)
+        ops.field_backward(*geo, d['fine'], streams, stash, rgbs, d_rgbs * 2.0 ** k, grad, d_z=d_z)
+        torch.cuda.synchronize()
+        assert torch.isfinite(grad).all() and torch.isfinite(d_z).all()
+        out[k] = (grad, d_z)
+    assert out[0][0].abs().max().item() > 0
+    for k in (-40, 13):
+        assert torch.equal(out[k][0], out[0][0] * 2.0 ** k), k
+        if views == 1:                                  # (V > 1: dL/dz accumulates over the views with fp32 atomics, order-dependent in the last bit)
+            assert torch.equal(out[k][1], out[0][1] * 2.0 ** k), k
+        else:
+            assert (out[k][1] - out[0][1] * 2.0 ** k).abs().max().item() <= 1e-5 * (out[0][1] * 2.0 ** k).abs().max().item()
