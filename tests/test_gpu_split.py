@@ -2,6 +2,8 @@
 pieces, six MFMAs per product, fp32 accumulation).  It replaces the fp32-MFMA kernel at the SAME bars: per-sample outputs
 and activations against the NumPy fp32 oracle, integer tap indices bit-exact, rendered outputs within the 1e-4 of
 north_star, on the direct and the texel-table path, 1..3 views, ragged tiles."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -123,7 +125,8 @@ def test_renderer_default_gemm_is_split_and_matches_mfma_f32():
     for gemm in ('split_f16', 'split_bf16'):
         for a, b in zip(outs[gemm], outs['mfma_f32']):
             assert float((a - b).abs().max()) < 2e-5
-    assert not all(torch.equal(a, b) for a, b in zip(outs['split_f16'], outs['split_bf16']))       # really two kernels
+    if not os.environ.get('MVNERF_SPLIT_MFMA'):                                                    # (the variable pins ONE kernel for every call)
+        assert not all(torch.equal(a, b) for a, b in zip(outs['split_f16'], outs['split_bf16']))   # really two kernels
     with pytest.raises(ValueError):
         MVVNeRFRenderer(64, 64, f32_gemm='tf32')
 
@@ -133,6 +136,8 @@ def test_products_of_the_three_fp32_grade_kernels_against_float64(monkeypatch):
     input activation (complete_output), so the difference is that block's two GEMMs alone - no geometry, no positional encoding.
     fp32 MFMA (v_mfma_f32_32x32x2_f32), six bf16 products on exactly cut operands (MVNERF_SPLIT_MFMA=bf16x6) and three fp16 products
     on two-piece operands (f16x3) must all sit at fp32 rounding level, and the fp16 form within 2x of the fp32 MFMA."""
+    if os.environ.get('MVNERF_SPLIT_MFMA'):
+        pytest.skip('MVNERF_SPLIT_MFMA pins one kernel for every call: nothing to compare')
     sc = make_scene(seed=91, n_views=1, height=24, width=28, n_rays=256, bias_scale=0.1)
     d = {k: dev(sc[k]) for k in ['rays_o', 'rays_d', 'images', 'features', 'intrinsics', 'extrinsics_inv', 'fine']}
     rng = np.random.default_rng(3)
