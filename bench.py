@@ -341,9 +341,17 @@ def main():
                 pass
 
     if args.train_steps > 0 and not bf16:
+        # the training legs are reported beside the headline, never instead of it: a failure in one of them (it would be the same on every
+        # rank: they run the same code on the same shapes) is recorded and the line is still printed
         if world == 1 and not strong:
-            result['train_step'] = train_throughput(sc, t, args.views, dev, args.train_steps)
-        leg = train_cfg4(rank, world, dev, backend, args.train_steps, barrier, red_dev, strong)
+            try:
+                result['train_step'] = train_throughput(sc, t, args.views, dev, args.train_steps)
+            except Exception as exc:               # noqa: BLE001
+                result['train_step'] = {'error': f'{type(exc).__name__}: {exc}'[:300]}
+        try:
+            leg = train_cfg4(rank, world, dev, backend, args.train_steps, barrier, red_dev, strong)
+        except Exception as exc:                   # noqa: BLE001
+            leg = {'error': f'{type(exc).__name__}: {exc}'[:300]}
         if rank == 0:
             result['train_cfg4'] = leg
     if rank == 0:
