@@ -341,6 +341,23 @@ int mvnerf_gemm_nt_bias(const float* a, const float* bt, const float* bias, floa
 size_t mvnerf_gemm_tn_scratch_bytes(int M, int N, int K);
 int mvnerf_gemm_tn(const float* g, const float* a, float* c, int M, int N, int K, void* scratch, mvnerf_stream_t stream);
 
+/* A batch of such weight gradients that share M, in one launch (+ one fixed-order reduce): for b < batch
+ *     c[b] (N,K) = G[b]^T A[b]  (+ G2[b]^T A2[b]),      colsum[b][n] = sum_m Gs[b][m][n]   (the bias gradient; Gs = G or G2)
+ * with G[b] = g + b * g_batch_stride (floats) and row stride ldg - a column block of a wider matrix is used where it lies -, likewise
+ * A, G2, A2.  This is what the weight gradients of GraspReadout's per-point layers need (delta_ngf/layers.py:8-42 under the nested tapes
+ * of lmvnerf/model_v4.py:290-322): four Dense(128 -> 64) on column blocks of one cotangent, and in the second-order pass the sum of two
+ * products per layer.  g2 / a2 may be NULL (one product).  colsum_of: 0 none, 1 G, 2 G2; colsum: batch * N floats.
+ * M % 8 == 0, N % 32 == 0, K % 64 == 0; scratch: mvnerf_gemm_tn_batched_scratch_bytes(M,N,K,batch,colsum_of != 0) bytes. */
+typedef struct mvnerf_gemm_tn_batch {
+    const float* g;  const float* a;  const float* g2;  const float* a2;
+    long g_batch_stride, a_batch_stride, g2_batch_stride, a2_batch_stride;
+    int ldg, lda, ldg2, lda2;
+    int colsum_of;
+} mvnerf_gemm_tn_batch;
+size_t mvnerf_gemm_tn_batched_scratch_bytes(int M, int N, int K, int batch, int with_colsum);
+int mvnerf_gemm_tn_batched(const mvnerf_gemm_tn_batch* q, float* c, float* colsum, int M, int N, int K, int batch, void* scratch,
+                           mvnerf_stream_t stream);
+
 /* ---- The trunk as a differentiable field on arbitrary query points. ----
  * Reference consumer: LanguageNeRF._call (lmvnerf/model_v4.py:208-265) evaluates fine_embedding on
  * camera_points / camera_directions derived from grasp poses and keeps outputs[4:] = (view mean, u1, u2, u3)

@@ -76,3 +76,32 @@ def test_wide_linear_first_and_second_derivatives_match_torch():
     small = torch.nn.Linear(64, 64).to(DEV)
     xs = torch.randn((4, 64), device=DEV)
     assert torch.equal(_wide_linear(small, xs), small(xs))
+
+
+@pytest.mark.parametrize('two_pairs,colsum_of', [(False, 0), (False, 1), (True, 2), (True, 1)])
+def test_gemm_tn_batched_matches_float64(two_pairs, colsum_of):
+    """mvnerf_gemm_tn_batched: a batch of weight gradients on column blocks of one cotangent, optionally the sum of two products, and
+    the bias gradient (column sums) from the same pass; operands read where they lie (no copies), results deterministic."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    m, batch, n, k = 4000, 4, 64, 128
+    gu = torch.randn((m, batch * n), device=DEV, generator=g)
+    a = torch.randn((batch, m, k), device=DEV, generator=g)
+    gu2 = torch.randn((m, batch * n), device=DEV, generator=g) if two_pairs else None
+    a2 = torch.randn((batch, m, k), device=DEV, generator=g) if two_pairs else None
+    blocks = lambda x: x.view(m, batch, n).permute(1, 0, 2)
+    out = ops.gemm_tn_batched(blocks(gu), a, g2=None if gu2 is None else blocks(gu2), a2=a2, colsum_of=colsum_of)
+    again = ops.gemm_tn_batched(blocks(gu), a, g2=None if gu2 is None else blocks(gu2), a2=a2, colsum_of=colsum_of)
+    c, cs = out if colsum_of else (out, None)
+    want = torch.einsum('bmn,bmk->bnk', blocks(gu).double(), a.double())
+    if two_pairs:
+        want = want + torch.einsum('bmn,bmk->bnk', blocks(gu2).double(), a2.double())
+    assert c.shape == (batch, n, k)
+    assert (c.double() - want).abs().max().item() < 2e-5 * want.abs().max().item()
+    if colsum_of:
+        src = gu if colsum_of == 1 else gu2
+        want_s = src.double().sum(0).view(batch, n)
+        assert (cs.double() - want_s).abs().max().item() < 2e-5 * want_s.abs().max().item()
+        assert torch.equal(cs, again[1])
+    assert torch.equal(c, again[0] if colsum_of else again)
+    with pytest.raises(ValueError):
+        ops.gemm_tn_batched(blocks(gu).transpose(1, 2), a)                       # rows not contiguous

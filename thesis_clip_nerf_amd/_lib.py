@@ -35,6 +35,13 @@ class AdamState(ctypes.Structure):
                 ('clip', c_float), ('update_mask', c_void_p), ('repack', c_int)]
 
 
+class GemmTnBatch(ctypes.Structure):
+    """mvnerf_gemm_tn_batch (include/mvnerf_hip.h)."""
+    _fields_ = ([(n, c_void_p) for n in ('g', 'a', 'g2', 'a2')] +
+                [(n, ctypes.c_long) for n in ('g_batch_stride', 'a_batch_stride', 'g2_batch_stride', 'a2_batch_stride')] +
+                [(n, c_int) for n in ('ldg', 'lda', 'ldg2', 'lda2', 'colsum_of')])
+
+
 # name -> (restype, argtypes); must list every symbol include/mvnerf_hip.h declares
 # (tests/test_abi.py cross-checks this table against the header and the built library).
 SIGNATURES = {
@@ -91,6 +98,8 @@ SIGNATURES = {
     'mvnerf_gemm_nt_scratch_bytes': (c_size_t, [c_int] * 3),
     'mvnerf_gemm_tn_scratch_bytes': (c_size_t, [c_int] * 3),
     'mvnerf_gemm_tn': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p] * 2),
+    'mvnerf_gemm_tn_batched_scratch_bytes': (c_size_t, [c_int] * 5),
+    'mvnerf_gemm_tn_batched': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 2),
     'mvnerf_gemm_nt': (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p] * 2),
     'mvnerf_gemm_nt_bias': (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 2),
     'mvnerf_field_backward_table': (c_int, [c_void_p] * 14 + [c_int] * 6 + [c_void_p] * 5),

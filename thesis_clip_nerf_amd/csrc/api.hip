@@ -671,6 +671,34 @@ int mvnerf_gemm_tn(const float* g, const float* a, float* c, int M, int N, int K
                       "mvnerf_gemm_tn");
 }
 
+size_t mvnerf_gemm_tn_batched_scratch_bytes(int M, int N, int K, int batch, int with_colsum) {
+    if (!gemm_tn_shape_ok(M, N, K) || batch <= 0) return 0;
+    return mvnerf::gemm_tn_batched_scratch_floats(M, N, K, batch, with_colsum != 0) * sizeof(float);
+}
+
+int mvnerf_gemm_tn_batched(const mvnerf_gemm_tn_batch* q, float* c, float* colsum, int M, int N, int K, int batch, void* scratch,
+                           mvnerf_stream_t stream) {
+    if (!q || !q->g || !q->a || !c) return fail(MVNERF_E_ARG, "mvnerf_gemm_tn_batched: null pointer");
+    if ((q->g2 == nullptr) != (q->a2 == nullptr)) return fail(MVNERF_E_ARG, "mvnerf_gemm_tn_batched: g2 and a2 come together");
+    if (!gemm_tn_shape_ok(M, N, K) || batch <= 0)
+        return fail(MVNERF_E_SHAPE, "mvnerf_gemm_tn_batched: M=%d N=%d K=%d batch=%d, needs M %% 8 == 0, N %% 32 == 0, K %% 64 == 0", M, N, K, batch);
+    if (q->ldg < N || q->lda < K || (q->g2 && (q->ldg2 < N || q->lda2 < K)))
+        return fail(MVNERF_E_SHAPE, "mvnerf_gemm_tn_batched: row strides ldg=%d lda=%d ldg2=%d lda2=%d below N=%d / K=%d", q->ldg, q->lda, q->ldg2, q->lda2, N, K);
+    if (q->colsum_of < 0 || q->colsum_of > 2 || (q->colsum_of == 2 && !q->g2) || (q->colsum_of != 0 && !colsum))
+        return fail(MVNERF_E_ARG, "mvnerf_gemm_tn_batched: colsum_of=%d without its operand or output", q->colsum_of);
+    if (!aligned16(c) || (colsum && !aligned16(colsum)) || (scratch && !aligned16(scratch)))
+        return fail(MVNERF_E_ALIGN, "mvnerf_gemm_tn_batched: c, colsum, scratch must be 16-byte aligned");
+    if (mvnerf_gemm_tn_batched_scratch_bytes(M, N, K, batch, q->colsum_of != 0) && !scratch)
+        return fail(MVNERF_E_ARG, "mvnerf_gemm_tn_batched: this shape needs scratch");
+    mvnerf::TnBatchArgs a;
+    a.G = q->g; a.A = q->a; a.G2 = q->g2; a.A2 = q->a2;
+    a.g_bstride = q->g_batch_stride; a.a_bstride = q->a_batch_stride; a.g2_bstride = q->g2_batch_stride; a.a2_bstride = q->a2_batch_stride;
+    a.ldg = q->ldg; a.lda = q->lda; a.ldg2 = q->ldg2; a.lda2 = q->lda2;
+    a.colsum_of = q->colsum_of;
+    return hip_status(mvnerf::launch_gemm_tn_batched(a, c, colsum, M, N, K, batch, static_cast<float*>(scratch), static_cast<hipStream_t>(stream)),
+                      "mvnerf_gemm_tn_batched");
+}
+
 // ---- the trunk as a differentiable field on query points --------------------------------------
 size_t mvnerf_query_workspace_bytes(int B, int V, int N) {
     if (B <= 0 || V <= 0 || N <= 0) return 0;

@@ -116,6 +116,15 @@ hipError_t launch_gemm_nt_f32(const float* A, const float* Bt, const float* bias
                               hipStream_t st);   // bias: N floats added to every row, or nullptr
 int gemm_nt_splits(int M, int N, int K);
 hipError_t launch_gemm_tn_f32(const float* G, const float* A, float* C, int M, int N, int K, float* scratch, hipStream_t st);
+// a batch of weight gradients sharing M: C[b] = G[b]^T A[b] (+ G2[b]^T A2[b]), optional column sums of G (colsum_of = 1) or G2 (= 2)
+struct TnBatchArgs {
+    const float* G; const float* A; const float* G2; const float* A2;
+    long g_bstride, a_bstride, g2_bstride, a2_bstride;
+    int ldg, lda, ldg2, lda2;
+    int colsum_of;
+};
+size_t gemm_tn_batched_scratch_floats(int M, int N, int K, int batch, bool colsum);
+hipError_t launch_gemm_tn_batched(const TnBatchArgs& a, float* C, float* colsum, int M, int N, int K, int batch, float* scratch, hipStream_t st);
 int gemm_tn_splits(int M, int N, int K);
 hipError_t launch_pack_bwd_streams(const float* net_keras, float* dst, hipStream_t st);
 hipError_t launch_field_dz(const FieldParams& p, const float* g0_tl, const float* w0t_streams, float* d_z, float* d_o,

@@ -183,6 +183,15 @@ def _gtn(g, a):
     return g.t() @ a
 
 
+def _batched_ok(g_u):
+    return g_u.is_cuda and g_u.dtype == torch.float32 and g_u.shape[0] % 8 == 0 and g_u.is_contiguous()
+
+
+def _col_blocks(x):
+    """(M, 4 * 64) -> the four (M, 64) column blocks as a (4, M, 64) view (strides 64, 256, 1): what mvnerf_gemm_tn_batched reads in place."""
+    return x.view(x.shape[0], 4, 64).permute(1, 0, 2)
+
+
 class _HeadVJP(torch.autograd.Function):
     """The vector-Jacobian product of the fused head as a differentiable function of its cotangent and of the weights: forward =
     mvnerf_grasp_head_vjp (+ the weight gradients as skinny GEMMs), backward = mvnerf_grasp_head_vjp_bwd - what the nested tape of
@@ -193,9 +202,14 @@ class _HeadVJP(torch.autograd.Function):
     def forward(ctx, g_y, acts, c, y, w4, b4, wc, bc, packed):
         g_y = g_y.contiguous()
         g_v, q, g_u, g_acts = ops.grasp_head_vjp(g_y, c, y, packed)
-        d_wc, d_bc = _gtn(g_v, c), g_v.sum(0)
-        d_w4 = torch.stack([_gtn(g_u[:, 64 * k:64 * k + 64], acts[k]) for k in range(4)])
-        d_b4 = g_u.sum(0).reshape(4, 64)
+        if _batched_ok(g_u):
+            # the five weight gradients and their bias gradients: two launches (+ fixed-order reduces), the column blocks of g_u read where they lie
+            d_w4, d_b4 = ops.gemm_tn_batched(_col_blocks(g_u), acts, colsum_of=1)
+            d_wc, d_bc = (t[0] for t in ops.gemm_tn_batched(g_v[None], c[None], colsum_of=1))
+        else:
+            d_wc, d_bc = _gtn(g_v, c), g_v.sum(0)
+            d_w4 = torch.stack([_gtn(g_u[:, 64 * k:64 * k + 64], acts[k]) for k in range(4)])
+            d_b4 = g_u.sum(0).reshape(4, 64)
         ctx.save_for_backward(g_y, acts, c, y, q, g_v, g_u, packed)
         ctx.set_materialize_grads(False)
         return g_acts, d_w4, d_b4, d_wc, d_bc
@@ -208,10 +222,14 @@ class _HeadVJP(torch.autograd.Function):
             return (None,) * 9
         g_y, acts, c, y, q, g_v, g_u, packed = ctx.saved_tensors
         out_gy, r, m, p_ = ops.grasp_head_vjp_bwd(t_acts.contiguous(), g_y, c, y, q, packed)
-        d_w4 = torch.stack([_gtn(g_u[:, 64 * k:64 * k + 64], t_acts[k]) + _gtn(p_[:, 64 * k:64 * k + 64], acts[k]) for k in range(4)])
-        d_b4 = p_.sum(0).reshape(4, 64)
-        d_wc = _gtn(g_v, r) + _gtn(m, c)
-        d_bc = m.sum(0)
+        if _batched_ok(g_u):
+            d_w4, d_b4 = ops.gemm_tn_batched(_col_blocks(g_u), t_acts.contiguous(), g2=_col_blocks(p_), a2=acts, colsum_of=2)
+            d_wc, d_bc = (t[0] for t in ops.gemm_tn_batched(g_v[None], r[None], g2=m[None], a2=c[None], colsum_of=2))
+        else:
+            d_w4 = torch.stack([_gtn(g_u[:, 64 * k:64 * k + 64], t_acts[k]) + _gtn(p_[:, 64 * k:64 * k + 64], acts[k]) for k in range(4)])
+            d_b4 = p_.sum(0).reshape(4, 64)
+            d_wc = _gtn(g_v, r) + _gtn(m, c)
+            d_bc = m.sum(0)
         return out_gy, None, None, None, d_w4, d_b4, d_wc, d_bc, None
 
 

@@ -738,6 +738,38 @@ def gemm_tn(g, a):
     return out
 
 
+def gemm_tn_batched(g, a, g2=None, a2=None, colsum_of=0):
+    """mvnerf_gemm_tn_batched: out[b] = g[b]^T @ a[b] (+ g2[b]^T @ a2[b]) for a batch of weight gradients that share their M rows, and the
+    column sums of g (colsum_of=1) or g2 (=2) from the same pass.  g, g2: (batch, M, N) views whose last dimension is contiguous - e.g.
+    `x.view(M, batch, N).permute(1, 0, 2)` for the column blocks of one (M, batch * N) matrix: no copies are made; a, a2: (batch, M, K).
+    -> (batch, N, K) [, (batch, N)]."""
+    def strides(t, name):
+        if t.dim() != 3 or t.stride(2) != 1 or t.dtype != torch.float32 or not t.is_cuda:
+            raise ValueError(f'{name}: needs a float32 device tensor (batch, M, cols) with contiguous rows')
+        return t.stride(0), t.stride(1)
+    batch, m, n = g.shape
+    k = a.shape[2]
+    if tuple(a.shape[:2]) != (batch, m):
+        raise ValueError(f'a: {tuple(a.shape)} does not match g {tuple(g.shape)}')
+    q = _lib.GemmTnBatch()
+    q.g, q.a = _p(g), _p(a)
+    (q.g_batch_stride, q.ldg), (q.a_batch_stride, q.lda) = strides(g, 'g'), strides(a, 'a')
+    if g2 is not None:
+        if tuple(g2.shape) != tuple(g.shape) or tuple(a2.shape) != tuple(a.shape):
+            raise ValueError('g2 / a2 must have the shapes of g / a')
+        q.g2, q.a2 = _p(g2), _p(a2)
+        (q.g2_batch_stride, q.ldg2), (q.a2_batch_stride, q.lda2) = strides(g2, 'g2'), strides(a2, 'a2')
+    q.colsum_of = int(colsum_of)
+    out = torch.empty((batch, n, k), dtype=torch.float32, device=a.device)
+    colsum = torch.empty((batch, n), dtype=torch.float32, device=a.device) if colsum_of else None
+    need = int(_lib.lib().mvnerf_gemm_tn_batched_scratch_bytes(m, n, k, batch, int(bool(colsum_of))))
+    scratch = torch.empty(need, dtype=torch.uint8, device=a.device) if need else None
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().mvnerf_gemm_tn_batched(ctypes.byref(q), _p(out), _p(colsum), m, n, k, batch, _p(scratch), _stream(a))
+    _lib.check(rc, 'gemm_tn_batched')
+    return (out, colsum) if colsum_of else out
+
+
 SPLIT_KERNELS = {'split_f16': 0, 'split_bf16': 1, 'split_bf16_32x32x16': 2}
 
 
