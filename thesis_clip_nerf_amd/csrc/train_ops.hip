@@ -1066,8 +1066,8 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(const float* __restric
                                                           float* __restrict__ g_tl, float* __restrict__ amax_out) {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= n_tiles) return;                           // (whole waves: a tile is a wave)
     float out_max = 0.0f;
+    if (tile < n_tiles) {
     const long row = tile * 32 + j;
     float dov[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (row < n_rows) {
@@ -1091,7 +1091,16 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(const float* __restric
         out_max = fmaxf(out_max, fabsf(gv));
         g_tl[o] = gv;
     }
-    amax_publish(amax_out, out_max);                       // max |g| for the fp16 cut of the first layer launch (dense_bwd_split8_kernel)
+    }                                                      // (a tile is a wave: waves past the last tile only take part in the reduction)
+    // max |g| for the fp16 cut of the first layer launch (dense_bwd_split8_kernel): one atomic per workgroup (4 096 workgroups share 64 slots)
+    __shared__ float wg_max[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) out_max = fmaxf(out_max, __shfl_xor(out_max, off));
+    if (lane == 0) wg_max[threadIdx.x >> 6] = out_max;
+    __syncthreads();
+    if (amax_out && threadIdx.x == 0)
+        atomicMax(reinterpret_cast<int*>(amax_out) + (blockIdx.x & (kAmaxSlots - 1)),
+                  __builtin_bit_cast(int, fmaxf(fmaxf(wg_max[0], wg_max[1]), fmaxf(wg_max[2], wg_max[3]))));
 }
 
 __global__ void zero_kernel(unsigned* __restrict__ p, size_t n) {
