@@ -380,6 +380,26 @@ def kl_divergence(y_true, y_pred):
     return (y_true * torch.log(y_true / y_pred)).sum(-1)
 
 
+def _quaternion_pose_map(offsets):
+    """rotation_from_quaternion is a quadratic form in q = (x, y, z, w): R_ik = delta_ik + sum_ab q_a q_b A[ab, ik].  Folded with the gripper
+    offsets, the query points and directions of ALL offsets are one product of the 16 pair products q_a q_b with a constant matrix:
+        points[o, i] = off_t[o, i] + t_i + sum_ab q_a q_b (A[ab, i, :] . off_t[o]),     dirs[o, i] = off_z[o, i] + sum_ab q_a q_b (A[ab, i, :] . off_z[o])
+    -> (16, 2 * n5 * 3) float32: columns [points (o, i) | dirs (o, i)].  Same polynomial as the reference's expression tree
+    (tensorflow_graphics from_quaternion, then transforms @ offsets: model_v4.py:67-101, 222-226), different summation order."""
+    a = np.zeros((4, 4, 3, 3))
+    x, y, z, w = 0, 1, 2, 3
+    def add(i, k, terms):
+        for (p, q, c) in terms:
+            a[p, q, i, k] += c
+    add(0, 0, [(y, y, -2), (z, z, -2)]); add(0, 1, [(x, y, 2), (z, w, -2)]); add(0, 2, [(x, z, 2), (y, w, 2)])
+    add(1, 0, [(x, y, 2), (z, w, 2)]); add(1, 1, [(x, x, -2), (z, z, -2)]); add(1, 2, [(y, z, 2), (x, w, -2)])
+    add(2, 0, [(x, z, 2), (y, w, -2)]); add(2, 1, [(y, z, 2), (x, w, 2)]); add(2, 2, [(x, x, -2), (y, y, -2)])
+    off_t, off_z = offsets[:, :3, 3].astype(np.float64), offsets[:, :3, 2].astype(np.float64)          # (n5, 3)
+    pts = np.einsum('pqik,ok->pqoi', a, off_t).reshape(16, -1)
+    drs = np.einsum('pqik,ok->pqoi', a, off_z).reshape(16, -1)
+    return np.concatenate([pts, drs], 1).astype(np.float32)
+
+
 class LanguageNeRF(nn.Module):
     """model_v4.py:37-330 without the encoders: `trunk_net` is the frozen fine_embedding (+ unused read-out) in the flat
     Keras order of MVVNeRFRenderer.fine_net; `combined_features` is passed in."""
@@ -396,6 +416,7 @@ class LanguageNeRF(nn.Module):
         self.register_buffer('trunk_net', torch.as_tensor(trunk_net, dtype=torch.float32).reshape(-1).clone())
         self.register_buffer('transforms_to_check', torch.from_numpy(grasp_offsets(n_5d_poses)))      # (n5,4,4)
         self.n_transforms_to_check = self.transforms_to_check.shape[0]
+        self.register_buffer('_pose_map', torch.from_numpy(_quaternion_pose_map(self.transforms_to_check.numpy())))   # (16, 2 n5 3)
         self.grasp_readout = GraspReadout(self.n_transforms_to_check, use_bias=True)
         self.translations = nn.Parameter(torch.zeros(batch_size, n_points_train, 3))
         rot_dim = 4 if rotation_representation == 'quaternion' else 6
@@ -448,13 +469,30 @@ class LanguageNeRF(nn.Module):
         b = transforms.shape[0]
         return points.reshape(b, -1, 3), dirs.reshape(b, -1, 3)                                     # query order (np, n5)
 
+    def _query_points_from_pose(self, translations, rotations):
+        """compute_matrices + _query_points for the quaternion representation in four launches instead of about thirty (and as many again
+        in each of the two backward passes): q (x) q, one (B np, 16) x (16, 6 n5) product, the offsets' constant, the translation."""
+        b, n_p = rotations.shape[:2]
+        n5 = self.n_transforms_to_check
+        qq = (rotations[..., :, None] * rotations[..., None, :]).reshape(b * n_p, 16)
+        both = (qq @ self._pose_map).reshape(b, n_p, 2, n5, 3)
+        off_t, off_z = self.transforms_to_check[:, :3, 3], self.transforms_to_check[:, :3, 2]
+        points = both[:, :, 0] + off_t + translations[:, :, None, :]
+        dirs = both[:, :, 1] + off_z
+        return points.reshape(b, -1, 3), dirs.reshape(b, -1, 3)
+
     def _call(self, inputs, transforms, n_points, batched_features, state=None):
         """model_v4.py:211-265: poses = transforms @ offsets; points = their translations, directions = their z axes;
         trunk -> fused activations (b, np, n5, 128) x 4 -> GraspReadout -> (B, np)."""
         state = state or self.trunk_state(inputs, batched_features)
-        points, dirs = self._query_points(transforms)
+        if transforms is None:                           # the training step: straight from the pose variables (quaternion representation)
+            points, dirs = self._query_points_from_pose(self.translations, self.rotations)
+            b = self.translations.shape[0]
+        else:
+            points, dirs = self._query_points(transforms)
+            b = transforms.shape[0]
         acts = TrunkField.apply(points, dirs, state)                                     # (4, B, np*n5, 128)
-        acts = acts.reshape(N_FUSED, transforms.shape[0], n_points, self.n_transforms_to_check, 128)
+        acts = acts.reshape(N_FUSED, b, n_points, self.n_transforms_to_check, 128)
         return self.grasp_readout(acts)
 
     def infer(self, inputs, transforms, n_points_infer, batched_features, compute_dtype='f32'):
@@ -481,12 +519,13 @@ class LanguageNeRF(nn.Module):
         lab = [torch.as_tensor(l, dtype=torch.float32).to(dev) for l in labels]
         state = self.trunk_state(inputs, combined_features)
         self.set_pose(inputs[0], inputs[1])
-        y_pred = self._call(inputs, self.compute_matrices(), self.n_points_train, combined_features, state)
+        fast = self.rotation_representation == 'quaternion'
+        y_pred = self._call(inputs, None if fast else self.compute_matrices(), self.n_points_train, combined_features, state)
         if self.softmax_before_loss:
             y_pred = torch.softmax(y_pred, -1)
         landscape_loss = self.loss(lab[0], y_pred)
         self.set_pose(inputs[2], inputs[3])
-        prediction = self._call(inputs, self.compute_matrices(), self.n_points_train, combined_features, state)
+        prediction = self._call(inputs, None if fast else self.compute_matrices(), self.n_points_train, combined_features, state)
         grads = torch.autograd.grad(prediction.sum(), self.pose_variables, create_graph=True)
         loss_t = cosine_similarity_loss(lab[1], grads[0])
         if self.rotation_representation == 'quaternion':
