@@ -44,6 +44,10 @@
 #ifndef MVS16_F16
 #error "include through field_eval_split16.hip / field_eval_split16h.hip"
 #endif
+#ifndef MVS16_MIXLO
+#define MVS16_MIXLO 0      // fp16 form: 1: the cut of a value pair with v_fma_mixlo / mixhi_f16, six vector instructions instead of eight
+#endif                     //    (bit-identical: scripts/mixlo_probe.hip).  Measured +0.5 % (profiles/r03_ab_f16x3_ablations.log) - and the pieces
+                           //    are then written by inline asm, whose hazards in front of an MFMA the compiler does not track: left off
 #if MVS16_F16
 #define MVS16_BYTES packed_net_split16h_bytes
 #define MVS16_PACK launch_pack_net_split16h
@@ -149,6 +153,19 @@ __device__ __forceinline__ void cut_pair(float v0, float v1, int q, B16& b) {
 #if MVS16_F16
     // p1 = B0 = rn16(v / 64), p3 = B1 = rn16(64 (v / 64 - B0)) = rn16(v - 64 B0): the remainder is exact in fp32, formed by one
     // mixed-precision fma per value (v_fma_mix_f32 reads B0's halves as they lie); p2 is not used
+#if MVS16_MIXLO
+    // four instructions per pair: v_fma_mixlo / mixhi_f16 form the product v / 64 (or the remainder v - 64 B0) in fp32 and round it ONCE
+    // to the fp16 half they write (scripts/mixlo_probe.hip: bit-identical to multiply + convert / fma + convert)
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h) : "v"(v0), "s"(0.015625f));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(v1), "s"(0.015625f));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "s"(-64.0f), "v"(v0));
+    // (the s_nop: the compiler's hazard recognizer does not see an inline-asm VALU write in front of an MFMA that reads the register - without
+    // the wait states the first MFMA behind a cut reads the old B1)
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1" : "+v"(l) : "v"(h), "s"(-64.0f), "v"(v1));
+    b.p1[q] = h;
+    b.p3[q] = l;
+#else
     const f32x2 t = {v0 * 0.015625f, v1 * 0.015625f};     // (forced into one v_pk_mul_f32 by inline asm: 2 % slower - the scheduler no longer places it)
     const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t, f16x2));
     float r0, r1;
@@ -157,6 +174,7 @@ __device__ __forceinline__ void cut_pair(float v0, float v1, int q, B16& b) {
     const f32x2 r = {r0, r1};
     b.p1[q] = h;
     b.p3[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+#endif
 #else
     const float r0 = v0 - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v0) & 0xffff0000u);
     const float r1 = v1 - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v1) & 0xffff0000u);
