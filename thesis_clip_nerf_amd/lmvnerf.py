@@ -149,6 +149,11 @@ class _LinearNT(torch.autograd.Function):
     def backward(ctx, g):
         a, w = ctx.saved_tensors
         ga = _MatmulNT.apply(g, w.t()) if ctx.needs_input_grad[0] else None
+        if (ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and not torch.is_grad_enabled() and g.is_cuda and g.dtype == torch.float32
+                and _tn_skinny(g.shape[0], g.shape[1], a.shape[1])):
+            # the last backward of a step (nothing differentiates it again): weight and bias gradient from one pass over g
+            gw, gb = (t[0] for t in ops.gemm_tn_batched(g.contiguous()[None], a.contiguous()[None], colsum_of=1))
+            return ga, gw, gb
         gw = _MatmulTN.apply(g, a) if ctx.needs_input_grad[1] else None
         gb = g.sum(0) if ctx.needs_input_grad[2] else None
         return ga, gw, gb
