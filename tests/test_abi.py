@@ -114,3 +114,25 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libmvnerf_hip.so')
     with pytest.raises(RuntimeError, match='no fallback'):
         _lib.lib()
+
+
+def test_round3_entry_points_validate_their_arguments():
+    lib = _lib.lib()
+    assert lib.mvnerf_set_split_kernel(7) == -1 and b'which=7' in lib.mvnerf_last_error()
+    prev = lib.mvnerf_set_split_kernel(1)
+    assert prev in (0, 1, 2) and lib.mvnerf_set_split_kernel(prev) == 1                 # returns the previous value
+    one = ctypes.c_void_p(16)
+    q = _lib.GemmTnBatch()
+    assert ctypes.sizeof(q) == 4 * 8 + 4 * 8 + 5 * 4 + 4                                  # the layout include/mvnerf_hip.h declares (LP64, padded)
+    assert lib.mvnerf_gemm_tn_batched(ctypes.byref(q), one, None, 64, 64, 64, 1, None, None) == -1        # null operands
+    q.g, q.a, q.ldg, q.lda = 16, 16, 64, 64
+    assert lib.mvnerf_gemm_tn_batched(ctypes.byref(q), one, None, 60, 64, 64, 1, None, None) == -2        # M % 8
+    assert lib.mvnerf_gemm_tn_batched(ctypes.byref(q), one, None, 64, 64, 64, 0, None, None) == -2        # batch
+    q.ldg = 32
+    assert lib.mvnerf_gemm_tn_batched(ctypes.byref(q), one, None, 64, 64, 64, 1, None, None) == -2 and b'row strides' in lib.mvnerf_last_error()
+    q.ldg, q.colsum_of = 64, 2
+    assert lib.mvnerf_gemm_tn_batched(ctypes.byref(q), one, one, 64, 64, 64, 1, None, None) == -1         # column sums of an absent G2
+    q.colsum_of = 1
+    assert lib.mvnerf_gemm_tn_batched(ctypes.byref(q), one, None, 64, 64, 64, 1, None, None) == -1        # ... without an output
+    assert lib.mvnerf_gemm_tn_batched_scratch_bytes(64512, 64, 128, 4, 1) > 0
+    assert lib.mvnerf_gemm_tn_batched_scratch_bytes(60, 64, 128, 4, 1) == 0
