@@ -278,7 +278,7 @@ __device__ __forceinline__ void ring16_load(Ring16& r, int start_chunk) {
 // kDma (inference): position p + 2 goes straight into slot (c + 2) % 3 by LDS-DMA - the slot of position p - 1, which nobody reads any
 //   more since the last barrier; the vmcnt(0) in front of the barrier at the k-step's end (ring16_next) lets it land before it is published;
 //   seven of the k-step's eight MFMA groups lie between the request and that wait.  No staging registers, no ds_write.
-// !kDma (training forward): through registers - store what the previous k-step loaded (position p + 2), load position p + 3 - because vmcnt
+// !kDma (MVS16_STASH_DMA = 0; the training forward's first form): through registers - store what the previous k-step loaded (position p + 2), load position p + 3 - because vmcnt
 //   retires in order: behind the stash's buffer_stores a vmcnt(0) per k-step would wait for 16 KiB of HBM writes per wave, whereas the
 //   staged loads are older than the stores that follow them.
 template <bool kDma>
@@ -593,7 +593,11 @@ struct SampleGeo {
 template <bool kMultiView, bool kProj, bool kAux, bool kStash>
 __global__ __launch_bounds__(512, 2) void MVS16_KERNEL(FieldParams p, const f32x4* __restrict__ wsplit) {
     constexpr int kW = 8;
-    constexpr bool kDma = MVS16_LDSDMA && !kStash;                           // see ring16_fetch
+#ifndef MVS16_STASH_DMA
+#define MVS16_STASH_DMA 1  // 1: the training forward's weight ring by LDS-DMA as well.  Its vmcnt(0) per k-step then also waits for the stash stores of
+#endif                     //    the layer boundary before it - on the fp16 form that costs less than the staging registers and LDS stores of the
+                           //    register-staged ring (train step 5.77 -> 5.74 ms, scripts/ab_train_libs.sh); 0: register-staged (round 3's first form)
+    constexpr bool kDma = MVS16_LDSDMA && (!kStash || MVS16_STASH_DMA);     // see ring16_fetch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s16[];
     constexpr int kRingBytes = kR16Slots * kR16SlotF4 * 16;                 // 72 KiB
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
