@@ -259,7 +259,8 @@ size_t mvnerf_stash_bytes(int B, int V, int R, int S);
  * and the only one.  The switch is kept for its callers: it records the flag and returns the previous value, nothing else.  The
  * gradients w.r.t. sample depths (V > 1), ray origins / directions and the source feature maps still accumulate with atomics. */
 int mvnerf_set_deterministic(int on);
-/* Bytes of scratch mvnerf_field_backward needs. */
+/* Bytes of scratch mvnerf_field_backward needs (three gradient tensors in tile layout, the read-out's cotangent tile, the per-workgroup
+ * weight-gradient partials and 14 x 64 floats of max |g| slots: the power-of-two scales of the layer launches' fp16 products). */
 size_t mvnerf_field_backward_scratch_bytes(int B, int V, int R, int S);
 
 /* mvnerf_field_eval in training mode: also stores the trunk's pre-activations into `stash`.
